@@ -1,0 +1,121 @@
+// Shared device helpers for the gfx950 kernels (wave64, MFMA fragments, counter-based dropout).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/gstvd_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+#define WAVE 64
+#define DEVFN __device__ __forceinline__
+
+DEVFN float to_f(float x) { return x; }
+DEVFN float to_f(bf16 x) { return (float)x; }
+template <typename T> DEVFN T from_f(float x);
+template <> DEVFN float from_f<float>(float x) { return x; }
+template <> DEVFN bf16 from_f<bf16>(float x) { return (bf16)x; }
+
+// ---- 4-element vector load/store of T as fp32 -------------------------------------------------
+DEVFN f32x4 ld4(const float* p) { return *(const f32x4*)p; }
+DEVFN f32x4 ld4(const bf16* p) {
+  bf16x4 v = *(const bf16x4*)p;
+  f32x4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  return r;
+}
+DEVFN void st4(float* p, f32x4 v) { *(f32x4*)p = v; }
+DEVFN void st4(bf16* p, f32x4 v) {
+  bf16x4 r = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+  *(bf16x4*)p = r;
+}
+
+// ---- wave reductions (64 lanes) ----------------------------------------------------------------
+DEVFN float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+DEVFN float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- counter-based dropout ----------------------------------------------------------------------
+// lowbias32 integer hash (full avalanche); one 32-bit draw serves two elements (16 bits each).
+DEVFN uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+struct DropKey {
+  uint32_t key, thr;   // keep iff u16 >= thr
+  float scale;         // 1/(1-p)
+  bool on;
+};
+DEVFN DropKey make_drop(float p, uint32_t site, const uint64_t* rng) {
+  DropKey k;
+  k.on = (p > 0.f) && (rng != nullptr);
+  k.thr = 0; k.scale = 1.f; k.key = 0;
+  if (k.on) {
+    uint64_t seed = rng[0], off = rng[1];
+    uint32_t a = mix32((uint32_t)seed ^ 0x9E3779B9u * (site + 1u));
+    uint32_t b = mix32((uint32_t)(seed >> 32) + 0x85EBCA6Bu * (uint32_t)off + site);
+    uint32_t c = mix32((uint32_t)(off >> 32) ^ (a + b));
+    k.key = a ^ (b * 0xC2B2AE35u) ^ c;
+    float t = p * 65536.f + 0.5f;
+    k.thr = (uint32_t)t;
+    k.scale = 1.f / (1.f - p);
+  }
+  return k;
+}
+DEVFN uint32_t drop_draw(const DropKey& k, uint64_t e2) {   // e2 = element index >> 1
+  uint32_t lo = (uint32_t)e2, hi = (uint32_t)(e2 >> 32);
+  return mix32((lo ^ k.key) + hi * 0x9E3779B1u);
+}
+DEVFN float drop_factor(const DropKey& k, uint64_t e) {     // scale if kept, 0 if dropped
+  if (!k.on) return 1.f;
+  uint32_t r = drop_draw(k, e >> 1);
+  uint32_t u = (e & 1) ? (r >> 16) : (r & 0xffffu);
+  return u >= k.thr ? k.scale : 0.f;
+}
+// four consecutive elements starting at e (e % 4 == 0)
+DEVFN f32x4 drop_factor4(const DropKey& k, uint64_t e) {
+  f32x4 f = {1.f, 1.f, 1.f, 1.f};
+  if (!k.on) return f;
+  uint32_t r0 = drop_draw(k, e >> 1), r1 = drop_draw(k, (e >> 1) + 1);
+  f[0] = (r0 & 0xffffu) >= k.thr ? k.scale : 0.f;
+  f[1] = (r0 >> 16) >= k.thr ? k.scale : 0.f;
+  f[2] = (r1 & 0xffffu) >= k.thr ? k.scale : 0.f;
+  f[3] = (r1 >> 16) >= k.thr ? k.scale : 0.f;
+  return f;
+}
+
+// ---- exact erf GELU (vilbert_dialog.py:115-121) -------------------------------------------------
+DEVFN float gelu_f(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
+DEVFN float dgelu_f(float x) {
+  float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// ---- MFMA wrappers: D(16x16) += A(16xK) * B(Kx16), fp32 accumulate ----------------------------
+// lane l: A[row l&15][k-slice l>>4], B[k-slice l>>4][col l&15]; D[row (l>>4)*4 + r][col l&15].
+DEVFN f32x4 mfma_bf16_k32(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+DEVFN f32x4 mfma_bf16_k16(s16x4 a, s16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
+DEVFN f32x4 mfma_f32_k4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// LDS transposed read: per 16-lane group a 4(row) x 16(col) block of 16-bit elements; lane 4q+p supplies
+// the address of row q, cols 4p..4p+3; lane i receives column i of the four rows.
+DEVFN s16x4 lds_tr16(const void* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+DEVFN s16x4 pack_bf16x4(float a, float b, float c, float d) {
+  bf16x4 v = {(bf16)a, (bf16)b, (bf16)c, (bf16)d};
+  return __builtin_bit_cast(s16x4, v);
+}
+
+#define GSTVD_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

@@ -1,0 +1,269 @@
+// MFMA GEMM for gfx950: C[m,n] = epi(alpha * sum_k A(m,k) B(n,k)), every nn.Linear fwd/dgrad/wgrad
+// on the gst-visdial enc_dec_a path (see include/gstvd_hip.h).
+//
+//  * bf16 inputs  -> v_mfma_f32_16x16x32_bf16, fp32 accumulate   (throughput mode)
+//  * fp32 inputs  -> v_mfma_f32_16x16x4_f32, exact fp32 fma chain (parity mode, 1e-4 logits gate)
+//  * operands are staged global -> registers -> LDS in 16-byte vectors, double buffered, one barrier
+//    per K tile; the next tile's global loads are in flight while the current tile is multiplied;
+//  * an operand may be row-major ([x][k], k contiguous) or k-major ([k][x]); the LDS image keeps the
+//    memory layout (straight, coalesced copy) and the MFMA fragment is read either with ds_read_b128
+//    (row-major, XOR-swizzled 16-byte slots) or with ds_read_b64_tr_b16 (k-major, XOR-swizzled 32-byte
+//    blocks) -- no transposing pass anywhere;
+//  * the MFMA is issued "swapped" (n on the accumulator rows) so each lane owns 4 consecutive n of one
+//    output row and the epilogue stores 8/16 bytes per lane.
+#include "common.h"
+
+struct GemmP {
+  const char* A; const char* B; char* C;
+  const float* bias; const char* addend; char* aux;
+  int64_t M, N, K, lda, ldb, ldc, ldadd, ldaux, sA, sB, sC, sAdd, sAux;
+  int epi; float alpha, p; uint32_t site; const uint64_t* rng;
+};
+
+template <typename T> struct TileCfg;
+template <> struct TileCfg<bf16> { static constexpr int VE = 8, BK = 64; };
+template <> struct TileCfg<float> { static constexpr int VE = 4, BK = 32; };
+
+// ---- LDS images -------------------------------------------------------------------------------
+// row-major image: BX rows of 128 bytes (BK elements); 16-byte slot s of row r lives at slot s ^ (r & 7)
+DEVFN int rm_off(int row, int slot) { return row * 128 + (((slot ^ row) & 7) << 4); }
+// k-major bf16 image: BK rows of BX*2 bytes; 32-byte block b of k-row r lives at block b ^ f(r)
+template <int BX> DEVFN int km_off_bf16(int krow, int col) {
+  constexpr int NB = BX / 16;
+  int f = (krow & 3) | (((krow >> 3) & 1) << 2);
+  int blk = ((col >> 4) ^ f) & (NB - 1);
+  return krow * (BX * 2) + (blk << 5) + ((col & 15) << 1);
+}
+template <int BX> constexpr int km_row_bytes_f32() { return (BX + 4) * 4; }
+
+template <typename T, int BX, bool KM> constexpr int image_bytes() {
+  return KM ? (sizeof(T) == 2 ? TileCfg<T>::BK * BX * 2 : TileCfg<T>::BK * km_row_bytes_f32<BX>()) : BX * 128;
+}
+
+// ---- global -> registers ----------------------------------------------------------------------
+template <typename T, int BX, bool KM, int NT, int NV>
+DEVFN void load_tile(u32x4 (&reg)[NV], const char* g, int64_t ld, int64_t x0, int64_t X, int64_t k0, int64_t K, int tid) {
+  constexpr int VE = TileCfg<T>::VE, BK = TileCfg<T>::BK;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int v = tid + i * NT;
+    int64_t x, k;
+    if (KM) { constexpr int VPR = BX / VE; k = k0 + v / VPR; x = x0 + (v % VPR) * VE; }
+    else    { constexpr int VPR = BK / VE; x = x0 + v / VPR; k = k0 + (v % VPR) * VE; }
+    u32x4 z = {0u, 0u, 0u, 0u};
+    if (x < X && k < K) {
+      const char* ptr = g + (KM ? (k * ld + x) : (x * ld + k)) * (int64_t)sizeof(T);
+      z = *(const u32x4*)ptr;
+    }
+    reg[i] = z;
+  }
+}
+// ---- registers -> LDS image ---------------------------------------------------------------------
+template <typename T, int BX, bool KM, int NT, int NV>
+DEVFN void store_tile(const u32x4 (&reg)[NV], char* img, int tid) {
+  constexpr int VE = TileCfg<T>::VE, BK = TileCfg<T>::BK;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int v = tid + i * NT;
+    int off;
+    if (KM) {
+      constexpr int VPR = BX / VE;
+      int kr = v / VPR, cv = v % VPR;
+      off = (sizeof(T) == 2) ? km_off_bf16<BX>(kr, cv * VE) : kr * km_row_bytes_f32<BX>() + cv * 16;
+    } else {
+      constexpr int VPR = BK / VE;
+      off = rm_off(v / VPR, v % VPR);
+    }
+    *(u32x4*)(img + off) = reg[i];
+  }
+}
+
+// ---- LDS image -> MFMA fragment ----------------------------------------------------------------
+// bf16: 8 elements k = kk*32 + 8g + j for x = xb + (lane & 15)
+template <int BX, bool KM> DEVFN bf16x8 frag_bf16(const char* img, int xb, int kk, int lane) {
+  int g = lane >> 4, li = lane & 15;
+  if (!KM) {
+    return *(const bf16x8*)(img + rm_off(xb + li, kk * 4 + g));
+  } else {
+    int kr = kk * 32 + 8 * g + (li >> 2), col = xb + 4 * (lane & 3);
+    s16x4 lo = lds_tr16(img + km_off_bf16<BX>(kr, col));
+    s16x4 hi = lds_tr16(img + km_off_bf16<BX>(kr + 4, col));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  }
+}
+// f32: one element k = ks*4 + g for x = xb + (lane & 15)
+template <int BX, bool KM> DEVFN float frag_f32(const char* img, int xb, int ks, int lane) {
+  int g = lane >> 4, li = lane & 15;
+  if (!KM) return *(const float*)(img + rm_off(xb + li, ks) + g * 4);
+  return *(const float*)(img + (ks * 4 + g) * km_row_bytes_f32<BX>() + (xb + li) * 4);
+}
+
+template <typename T, typename OT, int BM, int BN, int WM, int WN, bool AKM, bool BKM>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmP p) {
+  constexpr int VE = TileCfg<T>::VE, BK = TileCfg<T>::BK, NT = WM * WN * 64;
+  constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
+  constexpr int A_BYTES = image_bytes<T, BM, AKM>(), B_BYTES = image_bytes<T, BN, BKM>();
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int NVA = BM * BK / VE / NT, NVB = BN * BK / VE / NT;
+  static_assert(NVA >= 1 && NVB >= 1, "tile too small for the thread count");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int64_t z = blockIdx.z;
+  const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+  const char* gA = p.A + z * p.sA * (int64_t)sizeof(T);
+  const char* gB = p.B + z * p.sB * (int64_t)sizeof(T);
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  u32x4 ra[NVA], rb[NVB];
+  const int64_t nkt = (p.K + BK - 1) / BK;
+  load_tile<T, BM, AKM, NT, NVA>(ra, gA, p.lda, m0, p.M, 0, p.K, tid);
+  load_tile<T, BN, BKM, NT, NVB>(rb, gB, p.ldb, n0, p.N, 0, p.K, tid);
+  store_tile<T, BM, AKM, NT, NVA>(ra, smem, tid);
+  store_tile<T, BN, BKM, NT, NVB>(rb, smem + A_BYTES, tid);
+  __syncthreads();
+
+  for (int64_t t = 0; t < nkt; ++t) {
+    const char* cA = smem + (t & 1) * STAGE;
+    const char* cB = cA + A_BYTES;
+    const bool more = (t + 1 < nkt);
+    if (more) {
+      load_tile<T, BM, AKM, NT, NVA>(ra, gA, p.lda, m0, p.M, (t + 1) * BK, p.K, tid);
+      load_tile<T, BN, BKM, NT, NVB>(rb, gB, p.ldb, n0, p.N, (t + 1) * BK, p.K, tid);
+    }
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int kk = 0; kk < BK / 32; ++kk) {
+        bf16x8 fa[MI], fb[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) fa[i] = frag_bf16<BM, AKM>(cA, wm * WTM + i * 16, kk, lane);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) fb[j] = frag_bf16<BN, BKM>(cB, wn * WTN + j * 16, kk, lane);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) acc[i][j] = mfma_bf16_k32(fb[j], fa[i], acc[i][j]);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < BK / 4; ++ks) {
+        float fa[MI], fb[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) fa[i] = frag_f32<BM, AKM>(cA, wm * WTM + i * 16, ks, lane);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) fb[j] = frag_f32<BN, BKM>(cB, wn * WTN + j * 16, ks, lane);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) acc[i][j] = mfma_f32_k4(fb[j], fa[i], acc[i][j]);
+      }
+    }
+    if (more) {
+      char* nA = smem + ((t + 1) & 1) * STAGE;
+      store_tile<T, BM, AKM, NT, NVA>(ra, nA, tid);
+      store_tile<T, BN, BKM, NT, NVB>(rb, nA + A_BYTES, tid);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane owns C[m = .. + (lane&15)][n = .. + 4*(lane>>4) + 0..3] ---------------------
+  const int g = lane >> 4, li = lane & 15;
+  const DropKey dk = make_drop((p.epi & GSTVD_EPI_DROPOUT) ? p.p : 0.f, p.site, p.rng);
+  OT* C = (OT*)p.C + z * p.sC;
+  const OT* ADD = (const OT*)p.addend + z * p.sAdd;
+  T* AUX = (T*)p.aux + z * p.sAux;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int64_t m = m0 + wm * WTM + i * 16 + li;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int64_t n = n0 + wn * WTN + j * 16 + 4 * g;
+      if (n >= p.N) continue;
+      f32x4 v = acc[i][j] * p.alpha;
+      if (p.epi & GSTVD_EPI_BIAS) v += *(const f32x4*)(p.bias + n);
+      if (p.epi & GSTVD_EPI_ADD) v += ld4(ADD + m * p.ldadd + n);
+      if (p.epi & GSTVD_EPI_GELU) {
+        st4(AUX + m * p.ldaux + n, v);
+        v = (f32x4){gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])};
+      }
+      if (p.epi & GSTVD_EPI_DGELU) {
+        f32x4 u = ld4(AUX + m * p.ldaux + n);
+        v *= (f32x4){dgelu_f(u[0]), dgelu_f(u[1]), dgelu_f(u[2]), dgelu_f(u[3])};
+      }
+      if (dk.on) v *= drop_factor4(dk, (uint64_t)((z * p.M + m) * p.N + n));
+      st4(C + m * p.ldc + n, v);
+    }
+  }
+}
+
+template <typename K> static int ensure_lds(K kernel, int bytes) {
+  if (bytes <= 48 * 1024) return 0;
+  hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+template <typename T, typename OT, int BM, int BN, bool AKM, bool BKM>
+static int launch_cfg(const GemmP& p, int64_t batch, hipStream_t s) {
+  constexpr int WM = 2, WN = 2;
+  constexpr int lds = 2 * (image_bytes<T, BM, AKM>() + image_bytes<T, BN, BKM>());
+  auto k = gemm_kernel<T, OT, BM, BN, WM, WN, AKM, BKM>;
+  static int attr_rc = ensure_lds(k, lds);
+  if (attr_rc) return attr_rc;
+  dim3 grid((unsigned)((p.N + BN - 1) / BN), (unsigned)((p.M + BM - 1) / BM), (unsigned)batch);
+  hipLaunchKernelGGL(k, grid, dim3(WM * WN * 64), lds, s, p);
+  GSTVD_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T, typename OT, bool AKM, bool BKM>
+static int launch_layout(const GemmP& p, int64_t batch, hipStream_t s) {
+  // big tile when it still fills the chip, else the small one (M=592/400 streams, tiny test shapes)
+  int64_t big = ((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
+  if (p.M >= 256 && p.N >= 128 && big >= 96) return launch_cfg<T, OT, 128, 128, AKM, BKM>(p, batch, s);
+  return launch_cfg<T, OT, 64, 64, AKM, BKM>(p, batch, s);
+}
+
+template <typename T, typename OT>
+static int launch_dtype(const GemmP& p, int64_t batch, int akm, int bkm, hipStream_t s) {
+  if (!akm && !bkm) return launch_layout<T, OT, false, false>(p, batch, s);
+  if (!akm && bkm) return launch_layout<T, OT, false, true>(p, batch, s);
+  if (akm && bkm) return launch_layout<T, OT, true, true>(p, batch, s);
+  return launch_layout<T, OT, true, false>(p, batch, s);
+}
+
+extern "C" int gstvd_gemm(const gstvd_gemm_t* g, gstvd_stream_t stream) {
+  if (!g || !g->A || !g->B || !g->C) return GSTVD_E_NULL;
+  if (g->M <= 0 || g->N <= 0 || g->K <= 0 || g->batch <= 0) return GSTVD_E_SHAPE;
+  const int ve = g->dtype_in == GSTVD_BF16 ? 8 : 4;
+  if (g->N % 4) return GSTVD_E_SHAPE;
+  if (!g->a_kmajor && (g->K % ve)) return GSTVD_E_SHAPE;
+  if (!g->b_kmajor && (g->K % ve)) return GSTVD_E_SHAPE;
+  if (g->a_kmajor && (g->M % ve)) return GSTVD_E_SHAPE;
+  if (g->b_kmajor && (g->N % ve)) return GSTVD_E_SHAPE;
+  if ((g->lda % ve) || (g->ldb % ve) || (g->ldc % 4)) return GSTVD_E_ALIGN;
+  if (((uintptr_t)g->A | (uintptr_t)g->B | (uintptr_t)g->C) & 15) return GSTVD_E_ALIGN;
+  if ((g->epilogue & GSTVD_EPI_BIAS) && !g->bias) return GSTVD_E_NULL;
+  if ((g->epilogue & GSTVD_EPI_ADD) && !g->addend) return GSTVD_E_NULL;
+  if ((g->epilogue & (GSTVD_EPI_GELU | GSTVD_EPI_DGELU)) && !g->aux) return GSTVD_E_NULL;
+  GemmP p;
+  p.A = (const char*)g->A; p.B = (const char*)g->B; p.C = (char*)g->C;
+  p.bias = g->bias; p.addend = (const char*)g->addend; p.aux = (char*)g->aux;
+  p.M = g->M; p.N = g->N; p.K = g->K;
+  p.lda = g->lda; p.ldb = g->ldb; p.ldc = g->ldc; p.ldadd = g->ldadd; p.ldaux = g->ldaux;
+  p.sA = g->sA; p.sB = g->sB; p.sC = g->sC; p.sAdd = g->sAdd; p.sAux = g->sAux;
+  p.epi = g->epilogue; p.alpha = g->alpha; p.p = g->dropout_p; p.site = g->site; p.rng = g->rng;
+  hipStream_t s = (hipStream_t)stream;
+  if (g->dtype_in == GSTVD_BF16 && g->dtype_out == GSTVD_BF16) return launch_dtype<bf16, bf16>(p, g->batch, g->a_kmajor, g->b_kmajor, s);
+  if (g->dtype_in == GSTVD_BF16 && g->dtype_out == GSTVD_F32) return launch_dtype<bf16, float>(p, g->batch, g->a_kmajor, g->b_kmajor, s);
+  if (g->dtype_in == GSTVD_F32 && g->dtype_out == GSTVD_F32) return launch_dtype<float, float>(p, g->batch, g->a_kmajor, g->b_kmajor, s);
+  return GSTVD_E_DTYPE;
+}

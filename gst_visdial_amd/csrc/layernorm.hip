@@ -1,0 +1,373 @@
+// Fused dropout + residual + LayerNorm (forward/backward) and the two embedding front ends of the
+// ViLBERT-dialog encoder / BERT-generation decoder.  HBM-bound: one wave64 per row, 4-element (8/16 B)
+// vector accesses, row statistics by wave shuffles, dropout masks regenerated from the counter hash.
+// Reference arithmetic: models/vilbert_dialog.py:283-296 (TF-style LN), :324-352 (BertEmbeddingsDialog),
+// :1420-1427 (BertImageEmbeddings), :416-420 / :458-462 / :735-742 (dense -> dropout -> LN(x + residual)).
+#include "common.h"
+
+struct LnP {
+  gstvd_ln_t f;
+  // backward extras
+  const void* dy; int64_t lddy; void* dres; int64_t lddres; void* dx; int64_t lddx; float* partial;
+  float *dword, *dpos, *dtt, *dtt_ext;
+};
+
+constexpr int LN_BWD_RPB = 16;   // rows per block in backward (4 waves x 4 rows)
+
+// h = pre-LayerNorm row, 4 elements starting at column c
+template <typename T, int MODE>
+DEVFN f32x4 ln_prologue(const gstvd_ln_t& f, int64_t row, int c, const DropKey& dpre,
+                        int64_t id, int64_t tpos, int64_t seg, const float* locrow) {
+  f32x4 h;
+  if (MODE == GSTVD_LN_RESID) {
+    h = ld4((const T*)f.x + row * f.ldx + c);
+    h *= drop_factor4(dpre, (uint64_t)(row * f.H + c));
+    if (f.res) h += ld4((const T*)f.res + row * f.ldres + c);
+  } else if (MODE == GSTVD_LN_EMBED) {
+    h = *(const f32x4*)(f.word + id * f.H + c) + *(const f32x4*)(f.pos + tpos * f.H + c);
+    const float* trow = (seg < f.type_vocab) ? f.tt + seg * f.H : f.tt_ext + (seg - f.type_vocab) * f.H;
+    h += *(const f32x4*)(trow + c);
+  } else {
+    h = ld4((const T*)f.x + row * f.ldx + c);
+    f32x4 l = *(const f32x4*)(f.b_loc + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float* w = f.w_loc + (int64_t)(c + e) * 5;
+      float a = 0.f;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) a += locrow[j] * w[j];
+      l[e] += a;
+    }
+    h += l;
+  }
+  return h;
+}
+
+template <typename T, int MODE, int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(gstvd_ln_t f) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  if (row >= f.M) return;
+  const int H = (int)f.H;
+  const DropKey dpre = make_drop(MODE == GSTVD_LN_RESID ? f.p_pre : 0.f, f.site_pre, f.rng);
+  const DropKey dpost = make_drop(f.p_post, f.site_post, f.rng);
+  int64_t id = 0, tpos = 0, seg = 0;
+  float locrow[5] = {0, 0, 0, 0, 0};
+  if (MODE == GSTVD_LN_EMBED) { id = f.ids[row]; tpos = row % f.T; seg = f.segs ? f.segs[row] : 0; }
+  if (MODE == GSTVD_LN_IMAGE) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) locrow[j] = f.loc[row * 5 + j];
+  }
+  f32x4 h[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane * 4 + i * 256;
+    h[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (c < H) {
+      h[i] = ln_prologue<T, MODE>(f, row, c, dpre, id, tpos, seg, locrow);
+      s += h[i][0] + h[i][1] + h[i][2] + h[i][3];
+    }
+  }
+  const float mean = wave_sum(s) / (float)H;
+  float v = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane * 4 + i * 256;
+    if (c < H) {
+      f32x4 d = h[i] - mean;
+      v += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+    }
+  }
+  const float var = wave_sum(v) / (float)H;
+  const float rstd = 1.0f / sqrtf(var + f.eps);
+  if (lane == 0) { f.mean[row] = mean; f.rstd[row] = rstd; }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane * 4 + i * 256;
+    if (c < H) {
+      f32x4 y = *(const f32x4*)(f.gamma + c) * ((h[i] - mean) * rstd) + *(const f32x4*)(f.beta + c);
+      y *= drop_factor4(dpost, (uint64_t)(row * f.H + c));
+      st4((T*)f.y + row * f.ldy + c, y);
+    }
+  }
+}
+
+template <typename T, int MODE, int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(LnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = (float*)smem;                   // [3][H]
+  const gstvd_ln_t& f = p.f;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int H = (int)f.H;
+  for (int i = threadIdx.x; i < 3 * H; i += 256) red[i] = 0.f;
+  const DropKey dpre = make_drop(MODE == GSTVD_LN_RESID ? f.p_pre : 0.f, f.site_pre, f.rng);
+  const DropKey dpost = make_drop(f.p_post, f.site_post, f.rng);
+  f32x4 ag[NV], ab[NV], ax[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) ag[i] = ab[i] = ax[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int j = 0; j < LN_BWD_RPB / 4; ++j) {
+    const int64_t row = (int64_t)blockIdx.x * LN_BWD_RPB + wave + 4 * j;
+    if (row >= f.M) break;
+    int64_t id = 0, tpos = 0, seg = 0;
+    float locrow[5] = {0, 0, 0, 0, 0};
+    if (MODE == GSTVD_LN_EMBED) { id = f.ids[row]; tpos = row % f.T; seg = f.segs ? f.segs[row] : 0; }
+    if (MODE == GSTVD_LN_IMAGE) {
+#pragma unroll
+      for (int q = 0; q < 5; ++q) locrow[q] = f.loc[row * 5 + q];
+    }
+    const float mean = f.mean[row], rstd = f.rstd[row];
+    f32x4 xh[NV], gy[NV], dyv[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane * 4 + i * 256;
+      xh[i] = gy[i] = dyv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (c < H) {
+        f32x4 h = ln_prologue<T, MODE>(f, row, c, dpre, id, tpos, seg, locrow);
+        xh[i] = (h - mean) * rstd;
+        dyv[i] = ld4((const T*)p.dy + row * p.lddy + c) * drop_factor4(dpost, (uint64_t)(row * f.H + c));
+        gy[i] = dyv[i] * *(const f32x4*)(f.gamma + c);
+        s1 += gy[i][0] + gy[i][1] + gy[i][2] + gy[i][3];
+        f32x4 t = gy[i] * xh[i];
+        s2 += t[0] + t[1] + t[2] + t[3];
+      }
+    }
+    const float c1 = wave_sum(s1) / (float)H, c2 = wave_sum(s2) / (float)H;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane * 4 + i * 256;
+      if (c < H) {
+        f32x4 dh = (gy[i] - c1 - xh[i] * c2) * rstd;
+        ag[i] += dyv[i] * xh[i];
+        ab[i] += dyv[i];
+        if (MODE == GSTVD_LN_RESID) {
+          if (p.dres) st4((T*)p.dres + row * p.lddres + c, dh);
+          f32x4 dx = dh * drop_factor4(dpre, (uint64_t)(row * f.H + c));
+          if (p.dx && (p.dx != p.dres || dpre.on)) st4((T*)p.dx + row * p.lddx + c, dx);
+          ax[i] += dx;
+        } else if (MODE == GSTVD_LN_IMAGE) {
+          st4((T*)p.dres + row * p.lddres + c, dh);
+          ax[i] += dh;
+        } else {
+          float* tg = (seg < f.type_vocab) ? p.dtt + seg * f.H : p.dtt_ext + (seg - f.type_vocab) * f.H;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            atomicAdd(p.dword + id * f.H + c + e, dh[e]);
+            atomicAdd(p.dpos + tpos * f.H + c + e, dh[e]);
+            atomicAdd(tg + c + e, dh[e]);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane * 4 + i * 256;
+    if (c < H) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        atomicAdd(red + c + e, ag[i][e]);
+        atomicAdd(red + H + c + e, ab[i][e]);
+        if (MODE != GSTVD_LN_EMBED) atomicAdd(red + 2 * H + c + e, ax[i][e]);
+      }
+    }
+  }
+  __syncthreads();
+  float* out = p.partial + (int64_t)blockIdx.x * 3 * H;
+  for (int i = threadIdx.x; i < 3 * H; i += 256) out[i] = red[i];
+}
+
+// out_j[c] (+)= sum_b partial[b][j][c]; block = 64 columns x 4 row groups
+__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* partial, int64_t nblk, int64_t nvec, int64_t H,
+                                                              float* o0, float* o1, float* o2, int accumulate) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int64_t col = (int64_t)blockIdx.x * 64 + cl;      // over nvec*H
+  const int64_t W = nvec * H;
+  float a = 0.f;
+  if (col < W) {
+    const int64_t j = col / H, c = col % H;
+    const float* src = partial + j * H + c;
+    for (int64_t b = rg; b < nblk; b += 4) a += src[b * 3 * H];
+  }
+  red[rg][cl] = a;
+  __syncthreads();
+  if (rg == 0 && col < W) {
+    a = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+    const int64_t j = col / H, c = col % H;
+    float* o = j == 0 ? o0 : (j == 1 ? o1 : o2);
+    if (o) o[c] = accumulate ? o[c] + a : a;
+  }
+}
+
+// stage 1 of a plain column sum: block = 64-row slab x 256 columns -> partial[slab][N] (stride 3*N like LN partials? no: N)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_slab_kernel(const T* x, int64_t ldx, int64_t M, int64_t N, float* partial) {
+  __shared__ f32x4 red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 256 + lane * 4;
+  const int64_t r0 = (int64_t)blockIdx.y * 64;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  if (c < N) {
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+      int64_t r = r0 + wave + 4 * i;
+      if (r < M) a += ld4(x + r * ldx + c);
+    }
+  }
+  red[wave][lane] = a;
+  __syncthreads();
+  if (wave == 0 && c < N) {
+    a = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    *(f32x4*)(partial + (int64_t)blockIdx.y * N + c) = a;
+  }
+}
+// stage 2: out[c] (+)= sum_s partial[s][c]
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* partial, int64_t nslab, int64_t N, float* out, int accumulate) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + cl;
+  float a = 0.f;
+  if (c < N) for (int64_t s = rg; s < nslab; s += 4) a += partial[s * N + c];
+  red[rg][cl] = a;
+  __syncthreads();
+  if (rg == 0 && c < N) {
+    a = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+    out[c] = accumulate ? out[c] + a : a;
+  }
+}
+
+// dW_loc[h][j] += sum_m dh[m][h] loc[m][j]; grid (ceil(H/256), MS) with atomics
+template <typename T>
+__global__ __launch_bounds__(256) void locgrad_kernel(const T* dh, int64_t lddh, const float* loc, int64_t M, int64_t H, float* dw) {
+  const int64_t h = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (h >= H) return;
+  const int64_t per = (M + gridDim.y - 1) / gridDim.y;
+  const int64_t m0 = blockIdx.y * per, m1 = (m0 + per < M) ? m0 + per : M;
+  float a[5] = {0, 0, 0, 0, 0};
+  for (int64_t m = m0; m < m1; ++m) {
+    const float d = to_f(dh[m * lddh + h]);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) a[j] += d * loc[m * 5 + j];
+  }
+#pragma unroll
+  for (int j = 0; j < 5; ++j) atomicAdd(dw + h * 5 + j, a[j]);
+}
+
+// ---- host side -------------------------------------------------------------------------------------
+static int ln_check(const gstvd_ln_t* p) {
+  if (!p) return GSTVD_E_NULL;
+  if (p->dtype != GSTVD_F32 && p->dtype != GSTVD_BF16) return GSTVD_E_DTYPE;
+  if (p->M <= 0 || p->H <= 0 || (p->H % 4) || p->H > 2048) return GSTVD_E_SHAPE;
+  if (!p->gamma || !p->beta || !p->mean || !p->rstd) return GSTVD_E_NULL;
+  if (p->mode == GSTVD_LN_RESID) { if (!p->x) return GSTVD_E_NULL; }
+  else if (p->mode == GSTVD_LN_EMBED) { if (!p->ids || !p->word || !p->pos || !p->tt || !p->tt_ext || p->T <= 0) return GSTVD_E_NULL; }
+  else if (p->mode == GSTVD_LN_IMAGE) { if (!p->x || !p->loc || !p->w_loc || !p->b_loc) return GSTVD_E_NULL; }
+  else return GSTVD_E_UNSUPPORTED;
+  return 0;
+}
+
+template <typename T, int MODE>
+static int ln_fwd_nv(const gstvd_ln_t& f, hipStream_t s) {
+  dim3 grid((unsigned)((f.M + 3) / 4)), block(256);
+  if (f.H <= 256) hipLaunchKernelGGL((ln_fwd_kernel<T, MODE, 1>), grid, block, 0, s, f);
+  else if (f.H <= 768) hipLaunchKernelGGL((ln_fwd_kernel<T, MODE, 3>), grid, block, 0, s, f);
+  else if (f.H <= 1024) hipLaunchKernelGGL((ln_fwd_kernel<T, MODE, 4>), grid, block, 0, s, f);
+  else hipLaunchKernelGGL((ln_fwd_kernel<T, MODE, 8>), grid, block, 0, s, f);
+  GSTVD_LAUNCH_CHECK();
+  return 0;
+}
+template <typename T>
+static int ln_fwd_mode(const gstvd_ln_t& f, hipStream_t s) {
+  if (f.mode == GSTVD_LN_RESID) return ln_fwd_nv<T, GSTVD_LN_RESID>(f, s);
+  if (f.mode == GSTVD_LN_EMBED) return ln_fwd_nv<T, GSTVD_LN_EMBED>(f, s);
+  return ln_fwd_nv<T, GSTVD_LN_IMAGE>(f, s);
+}
+extern "C" int gstvd_ln_fwd(const gstvd_ln_t* p, gstvd_stream_t stream) {
+  int rc = ln_check(p);
+  if (rc) return rc;
+  if (!p->y) return GSTVD_E_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  return p->dtype == GSTVD_BF16 ? ln_fwd_mode<bf16>(*p, s) : ln_fwd_mode<float>(*p, s);
+}
+
+extern "C" int64_t gstvd_ln_bwd_blocks(int64_t M) { return (M + LN_BWD_RPB - 1) / LN_BWD_RPB; }
+
+template <typename T, int MODE>
+static int ln_bwd_nv(const LnP& p, hipStream_t s) {
+  dim3 grid((unsigned)gstvd_ln_bwd_blocks(p.f.M)), block(256);
+  size_t lds = (size_t)3 * p.f.H * sizeof(float);
+  if (p.f.H <= 256) hipLaunchKernelGGL((ln_bwd_kernel<T, MODE, 1>), grid, block, lds, s, p);
+  else if (p.f.H <= 768) hipLaunchKernelGGL((ln_bwd_kernel<T, MODE, 3>), grid, block, lds, s, p);
+  else if (p.f.H <= 1024) hipLaunchKernelGGL((ln_bwd_kernel<T, MODE, 4>), grid, block, lds, s, p);
+  else hipLaunchKernelGGL((ln_bwd_kernel<T, MODE, 8>), grid, block, lds, s, p);
+  GSTVD_LAUNCH_CHECK();
+  return 0;
+}
+template <typename T>
+static int ln_bwd_mode(const LnP& p, hipStream_t s) {
+  if (p.f.mode == GSTVD_LN_RESID) return ln_bwd_nv<T, GSTVD_LN_RESID>(p, s);
+  if (p.f.mode == GSTVD_LN_EMBED) return ln_bwd_nv<T, GSTVD_LN_EMBED>(p, s);
+  return ln_bwd_nv<T, GSTVD_LN_IMAGE>(p, s);
+}
+extern "C" int gstvd_ln_bwd(const gstvd_ln_bwd_t* b, gstvd_stream_t stream) {
+  if (!b) return GSTVD_E_NULL;
+  int rc = ln_check(&b->f);
+  if (rc) return rc;
+  if (!b->dy || !b->partial) return GSTVD_E_NULL;
+  if (b->f.mode == GSTVD_LN_EMBED && (!b->dword || !b->dpos || !b->dtt || !b->dtt_ext)) return GSTVD_E_NULL;
+  if (b->f.mode == GSTVD_LN_IMAGE && !b->dres) return GSTVD_E_NULL;
+  LnP p;
+  p.f = b->f; p.dy = b->dy; p.lddy = b->lddy; p.dres = b->dres; p.lddres = b->lddres;
+  p.dx = b->dx; p.lddx = b->lddx; p.partial = b->partial;
+  p.dword = b->dword; p.dpos = b->dpos; p.dtt = b->dtt; p.dtt_ext = b->dtt_ext;
+  hipStream_t s = (hipStream_t)stream;
+  return b->f.dtype == GSTVD_BF16 ? ln_bwd_mode<bf16>(p, s) : ln_bwd_mode<float>(p, s);
+}
+
+extern "C" int gstvd_colsum_partials(const float* partial, int64_t nblk, int64_t nvec, int64_t H,
+                                     float* out0, float* out1, float* out2, int32_t accumulate, gstvd_stream_t stream) {
+  if (!partial) return GSTVD_E_NULL;
+  if (nblk <= 0 || nvec <= 0 || nvec > 3 || H <= 0) return GSTVD_E_SHAPE;
+  dim3 grid((unsigned)((nvec * H + 63) / 64));
+  hipLaunchKernelGGL(colsum_partials_kernel, grid, dim3(256), 0, (hipStream_t)stream, partial, nblk, nvec, H, out0, out1, out2, accumulate);
+  GSTVD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gstvd_colsum(const void* x, int64_t ldx, int64_t M, int64_t N, int32_t dtype, float* out,
+                            float* scratch, int64_t scratch_elems, int32_t accumulate, gstvd_stream_t stream) {
+  if (!x || !out || !scratch) return GSTVD_E_NULL;
+  if (M <= 0 || N <= 0 || (N % 4)) return GSTVD_E_SHAPE;
+  const int64_t nslab = (M + 63) / 64;
+  if (scratch_elems < nslab * N) return GSTVD_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)((N + 255) / 256), (unsigned)nslab);
+  if (dtype == GSTVD_BF16) hipLaunchKernelGGL(colsum_slab_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)x, ldx, M, N, scratch);
+  else if (dtype == GSTVD_F32) hipLaunchKernelGGL(colsum_slab_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ldx, M, N, scratch);
+  else return GSTVD_E_DTYPE;
+  GSTVD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, s, scratch, nslab, N, out, accumulate);
+  GSTVD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gstvd_locgrad(const void* dh, int64_t lddh, const float* loc, int64_t M, int64_t H, int32_t dtype,
+                             float* dw_loc, int32_t accumulate, gstvd_stream_t stream) {
+  if (!dh || !loc || !dw_loc) return GSTVD_E_NULL;
+  if (M <= 0 || H <= 0) return GSTVD_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(dw_loc, 0, (size_t)H * 5 * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+  }
+  dim3 grid((unsigned)((H + 255) / 256), 16);
+  if (dtype == GSTVD_BF16) hipLaunchKernelGGL(locgrad_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dh, lddh, loc, M, H, dw_loc);
+  else if (dtype == GSTVD_F32) hipLaunchKernelGGL(locgrad_kernel<float>, grid, dim3(256), 0, s, (const float*)dh, lddh, loc, M, H, dw_loc);
+  else return GSTVD_E_DTYPE;
+  GSTVD_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,236 @@
+// LM-head cross entropy (visual_dialog_decoder.py:70-77), candidate scoring (evaluate_gen.py:94-106),
+// casts, the dropout-mask probe used by tests, and the fused AdamW (pytorch_transformers 1.2.0 semantics).
+// All HBM-bound: 16-byte vector accesses, one workgroup per logits row, deterministic reductions.
+#include "common.h"
+#include <math.h>
+
+DEVFN float block_reduce(float v, float* red, bool is_max) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  v = is_max ? wave_max(v) : wave_sum(v);
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float r = red[0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = is_max ? fmaxf(r, red[w]) : r + red[w];
+  return r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const T* logits, int64_t ldl, const int64_t* labels, int64_t V,
+                                                     int64_t ignore, float* row_loss, float* lse_out) {
+  __shared__ float red[4];
+  const int64_t m = blockIdx.x;
+  const T* x = logits + m * ldl;
+  const int64_t V4 = V & ~(int64_t)3;
+  float mx = -INFINITY;
+  for (int64_t c = threadIdx.x * 4; c < V4; c += 1024) {
+    f32x4 v = ld4(x + c);
+    mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+  }
+  for (int64_t c = V4 + threadIdx.x; c < V; c += 256) mx = fmaxf(mx, to_f(x[c]));
+  mx = block_reduce(mx, red, true);
+  float s = 0.f;
+  for (int64_t c = threadIdx.x * 4; c < V4; c += 1024) {
+    f32x4 v = ld4(x + c);
+    s += __expf(v[0] - mx) + __expf(v[1] - mx) + __expf(v[2] - mx) + __expf(v[3] - mx);
+  }
+  for (int64_t c = V4 + threadIdx.x; c < V; c += 256) s += __expf(to_f(x[c]) - mx);
+  s = block_reduce(s, red, false);
+  if (threadIdx.x == 0) {
+    const float lse = mx + logf(s);
+    lse_out[m] = lse;
+    const int64_t lab = labels[m];
+    row_loss[m] = (lab == ignore || lab < 0 || lab >= V) ? 0.f : lse - to_f(x[lab]);
+  }
+}
+
+// stats[0] = sum(row_loss), stats[1] = #(label != ignore); single block, fixed order => deterministic
+__global__ __launch_bounds__(256) void ce_reduce_kernel(const float* row_loss, const int64_t* labels, int64_t M,
+                                                        int64_t ignore, float* stats) {
+  __shared__ float red[4];
+  float s = 0.f, n = 0.f;
+  for (int64_t i = threadIdx.x; i < M; i += 256) {
+    s += row_loss[i];
+    n += (labels[i] != ignore) ? 1.f : 0.f;
+  }
+  s = block_reduce(s, red, false);
+  n = block_reduce(n, red, false);
+  if (threadIdx.x == 0) { stats[0] = s; stats[1] = n; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const T* logits, int64_t ldl, const int64_t* labels, const float* lse,
+                                                     const float* stats, const float* gscale, int mean, int64_t V,
+                                                     int64_t ignore, T* dl, int64_t ldd) {
+  const int64_t m = blockIdx.x;
+  const T* x = logits + m * ldl;
+  T* d = dl + m * ldd;
+  const int64_t lab = labels[m];
+  const bool keep = !(lab == ignore || lab < 0 || lab >= V);
+  float gs = gscale ? gscale[0] : 1.f;
+  if (mean) gs /= stats[1];
+  const float l = lse[m];
+  for (int64_t c = threadIdx.x * 4; c < ldd; c += 1024) {
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    if (keep) {
+      if (c + 3 < V) {
+        f32x4 v = ld4(x + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (__expf(v[e] - l) - ((c + e) == lab ? 1.f : 0.f)) * gs;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (c + e < V) o[e] = (__expf(to_f(x[c + e]) - l) - ((c + e) == lab ? 1.f : 0.f)) * gs;
+      }
+    }
+    st4(d + c, o);
+  }
+}
+
+// score[row] = sum_u [tgt != 0] (logits[row,u,tgt] - lse[row,u]),  tgt = ids[row,u+1] (0 for the last u)
+template <typename T>
+__global__ __launch_bounds__(64) void answer_scores_kernel(const T* logits, int64_t ldl, const float* lse,
+                                                           const int64_t* ids, int64_t U, float* scores) {
+  const int64_t row = blockIdx.x;
+  float a = 0.f;
+  for (int64_t u = threadIdx.x; u < U; u += 64) {
+    const int64_t tgt = (u + 1 < U) ? ids[row * U + u + 1] : 0;
+    if (tgt != 0) a += to_f(logits[(row * U + u) * ldl + tgt]) - lse[row * U + u];
+  }
+  a = wave_sum(a);
+  if (threadIdx.x == 0) scores[row] = a;
+}
+
+template <typename S, typename Dt>
+__global__ __launch_bounds__(256) void cast_kernel(const S* src, Dt* dst, int64_t n) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < n) st4(dst + i, ld4(src + i));
+  else for (int64_t j = i; j < n; ++j) dst[j] = from_f<Dt>(to_f(src[j]));
+}
+
+__global__ void scale_kernel(float* x, const float* f, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) x[i] *= f[0];
+}
+__global__ void rng_advance_kernel(uint64_t* rng) { rng[1] += 1; }
+__global__ void dropout_mask_kernel(float* out, int64_t n, float p, uint32_t site, const uint64_t* rng) {
+  const DropKey dk = make_drop(p, site, rng);
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = drop_factor(dk, (uint64_t)i);
+}
+
+// AdamW: pytorch_transformers==1.2.0 optimization.AdamW.step (train_gen.py:16,247)
+__global__ __launch_bounds__(256) void adamw_kernel(float* param, const float* grad, float* m, float* v, bf16* shadow, int64_t n,
+                                                    const int64_t* seg_end, const float* hp, int64_t nseg, float b1, float b2,
+                                                    float eps, const float* step, float gscale) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  int64_t lo = 0, hi = nseg - 1;                       // first segment whose end > i
+  while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (seg_end[mid] > i) hi = mid; else lo = mid + 1; }
+  const float t = step[0];
+  const float bc = sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
+  int64_t seg = lo;
+  for (int e = 0; e < 4 && i + e < n; ++e) {
+    const int64_t k = i + e;
+    while (seg < nseg - 1 && seg_end[seg] <= k) ++seg;
+    const float lr = hp[2 * seg], wd = hp[2 * seg + 1];
+    const float gg = grad[k] * gscale;
+    const float mm = m[k] * b1 + (1.f - b1) * gg;
+    const float vv = v[k] * b2 + (1.f - b2) * gg * gg;
+    m[k] = mm; v[k] = vv;
+    float pp = param[k] - lr * bc * (mm / (sqrtf(vv) + eps));
+    if (wd > 0.f) pp += -lr * wd * pp;
+    param[k] = pp;
+    if (shadow) shadow[k] = (bf16)pp;
+  }
+}
+
+// ---- C ABI ----------------------------------------------------------------------------------------------
+extern "C" int gstvd_abi_version(void) { return 1; }
+extern "C" const char* gstvd_build_arch(void) { return "gfx950"; }
+
+extern "C" int gstvd_ce_fwd(const void* logits, int64_t ldl, const int64_t* labels, int64_t M, int64_t V, int64_t ignore_index,
+                            int32_t dtype, float* row_loss, float* lse, float* stats, gstvd_stream_t stream) {
+  if (!logits || !labels || !row_loss || !lse || !stats) return GSTVD_E_NULL;
+  if (M <= 0 || V <= 0 || (ldl % 4)) return GSTVD_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == GSTVD_BF16) hipLaunchKernelGGL(ce_fwd_kernel<bf16>, dim3((unsigned)M), dim3(256), 0, s, (const bf16*)logits, ldl, labels, V, ignore_index, row_loss, lse);
+  else if (dtype == GSTVD_F32) hipLaunchKernelGGL(ce_fwd_kernel<float>, dim3((unsigned)M), dim3(256), 0, s, (const float*)logits, ldl, labels, V, ignore_index, row_loss, lse);
+  else return GSTVD_E_DTYPE;
+  GSTVD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(256), 0, s, row_loss, labels, M, ignore_index, stats);
+  GSTVD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gstvd_ce_bwd(const void* logits, int64_t ldl, const int64_t* labels, const float* lse, const float* stats,
+                            const float* gscale, int32_t mean, int64_t M, int64_t V, int64_t ignore_index, int32_t dtype,
+                            void* dlogits, int64_t ldd, gstvd_stream_t stream) {
+  if (!logits || !labels || !lse || !stats || !dlogits) return GSTVD_E_NULL;
+  if (M <= 0 || V <= 0 || (ldl % 4) || (ldd % 4) || ldd < V) return GSTVD_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == GSTVD_BF16) hipLaunchKernelGGL(ce_bwd_kernel<bf16>, dim3((unsigned)M), dim3(256), 0, s, (const bf16*)logits, ldl, labels, lse, stats, gscale, mean, V, ignore_index, (bf16*)dlogits, ldd);
+  else if (dtype == GSTVD_F32) hipLaunchKernelGGL(ce_bwd_kernel<float>, dim3((unsigned)M), dim3(256), 0, s, (const float*)logits, ldl, labels, lse, stats, gscale, mean, V, ignore_index, (float*)dlogits, ldd);
+  else return GSTVD_E_DTYPE;
+  GSTVD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gstvd_answer_scores(const void* logits, int64_t ldl, const float* lse, const int64_t* dec_ids, int64_t rows,
+                                   int64_t U, int32_t dtype, float* scores, gstvd_stream_t stream) {
+  if (!logits || !lse || !dec_ids || !scores) return GSTVD_E_NULL;
+  if (rows <= 0 || U <= 0) return GSTVD_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == GSTVD_BF16) hipLaunchKernelGGL(answer_scores_kernel<bf16>, dim3((unsigned)rows), dim3(64), 0, s, (const bf16*)logits, ldl, lse, dec_ids, U, scores);
+  else if (dtype == GSTVD_F32) hipLaunchKernelGGL(answer_scores_kernel<float>, dim3((unsigned)rows), dim3(64), 0, s, (const float*)logits, ldl, lse, dec_ids, U, scores);
+  else return GSTVD_E_DTYPE;
+  GSTVD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gstvd_cast(const void* src, int32_t sdt, void* dst, int32_t ddt, int64_t n, gstvd_stream_t stream) {
+  if (!src || !dst) return GSTVD_E_NULL;
+  if (n <= 0) return GSTVD_E_SHAPE;
+  if (((uintptr_t)src | (uintptr_t)dst) & 15) return GSTVD_E_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)((n + 1023) / 1024));
+  if (sdt == GSTVD_F32 && ddt == GSTVD_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16>), grid, dim3(256), 0, s, (const float*)src, (bf16*)dst, n);
+  else if (sdt == GSTVD_BF16 && ddt == GSTVD_F32) hipLaunchKernelGGL((cast_kernel<bf16, float>), grid, dim3(256), 0, s, (const bf16*)src, (float*)dst, n);
+  else if (sdt == GSTVD_F32 && ddt == GSTVD_F32) hipLaunchKernelGGL((cast_kernel<float, float>), grid, dim3(256), 0, s, (const float*)src, (float*)dst, n);
+  else if (sdt == GSTVD_BF16 && ddt == GSTVD_BF16) hipLaunchKernelGGL((cast_kernel<bf16, bf16>), grid, dim3(256), 0, s, (const bf16*)src, (bf16*)dst, n);
+  else return GSTVD_E_DTYPE;
+  GSTVD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gstvd_scale(float* x, const float* factor, int64_t n, gstvd_stream_t stream) {
+  if (!x || !factor) return GSTVD_E_NULL;
+  if (n <= 0) return GSTVD_E_SHAPE;
+  hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, factor, n);
+  GSTVD_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int gstvd_rng_advance(uint64_t* rng, gstvd_stream_t stream) {
+  if (!rng) return GSTVD_E_NULL;
+  hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rng);
+  GSTVD_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int gstvd_dropout_mask(float* out, int64_t n, float p, uint32_t site, const uint64_t* rng, gstvd_stream_t stream) {
+  if (!out || !rng) return GSTVD_E_NULL;
+  if (n <= 0) return GSTVD_E_SHAPE;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, n, p, site, rng);
+  GSTVD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gstvd_adamw(float* param, const float* grad, float* m, float* v, void* shadow_bf16, int64_t n,
+                           const int64_t* seg_end, const float* hp, int64_t nseg, float beta1, float beta2, float eps,
+                           const float* step, float grad_scale, gstvd_stream_t stream) {
+  if (!param || !grad || !m || !v || !seg_end || !hp || !step) return GSTVD_E_NULL;
+  if (n <= 0 || nseg <= 0) return GSTVD_E_SHAPE;
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v,
+                     (bf16*)shadow_bf16, n, seg_end, hp, nseg, beta1, beta2, eps, step, grad_scale);
+  GSTVD_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,208 @@
+"""Thin tensor-level wrappers over the C ABI (include/gstvd_hip.h).
+
+torch is used only as the owner of device memory and of the HIP stream; every function here launches
+a hand-written gfx950 kernel on `torch.cuda.current_stream()` and raises if the library is missing,
+a tensor is not on the GPU, or the kernel returns a non-zero status.  No fallbacks.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import F32, BF16, EPI_BIAS, EPI_ADD, EPI_GELU, EPI_DGELU, EPI_DROPOUT, LN_RESID, LN_EMBED, LN_IMAGE  # noqa: F401
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def dt(t):
+    return _DT[t.dtype]
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise L.GstvdError("gst_visdial_amd ops need GPU tensors (got %s); there is no CPU path" % t.device)
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Rng:
+    """Device-resident (seed, offset) pair read by every dropout site; graph-capture safe."""
+
+    def __init__(self, device, seed=0):
+        self.state = torch.tensor([seed, 0], dtype=torch.int64, device=device)
+
+    def advance(self):
+        lib = L.load()
+        L.check("gstvd_rng_advance", lib.gstvd_rng_advance(self.state.data_ptr(), _stream()))
+
+    def ptr(self):
+        return self.state.data_ptr()
+
+
+def gemm(A, B, C_out, M, N, K, *, a_km=False, b_km=False, bias=None, addend=None, aux=None, epi=0,
+         alpha=1.0, lda=None, ldb=None, ldc=None, ldadd=None, ldaux=None, batch=1, sA=0, sB=0, sC=0, sAdd=0, sAux=0,
+         drop_p=0.0, site=0, rng=None):
+    """C[M,N] = epi(alpha * A(m,k) B(n,k)); see gstvd_gemm in include/gstvd_hip.h.  Leading dimensions
+    default to the tensors' row strides."""
+    lib = L.load()
+    d = L.GemmDesc()
+    d.A, d.B, d.C = _p(A), _p(B), _p(C_out)
+    d.bias, d.addend, d.aux = _p(bias), _p(addend), _p(aux)
+    d.M, d.N, d.K = M, N, K
+    d.lda = A.stride(-2) if lda is None else lda
+    d.ldb = B.stride(-2) if ldb is None else ldb
+    d.ldc = C_out.stride(-2) if ldc is None else ldc
+    d.ldadd = (addend.stride(-2) if addend is not None else 0) if ldadd is None else ldadd
+    d.ldaux = (aux.stride(-2) if aux is not None else 0) if ldaux is None else ldaux
+    d.batch, d.sA, d.sB, d.sC, d.sAdd, d.sAux = batch, sA, sB, sC, sAdd, sAux
+    d.dtype_in, d.dtype_out = dt(A), dt(C_out)
+    d.a_kmajor, d.b_kmajor = int(a_km), int(b_km)
+    if bias is not None:
+        epi |= EPI_BIAS
+    if addend is not None:
+        epi |= EPI_ADD
+    if drop_p > 0:
+        epi |= EPI_DROPOUT
+    d.epilogue = epi
+    d.alpha, d.dropout_p, d.site = alpha, drop_p, site
+    d.rng = rng.ptr() if (rng is not None and drop_p > 0) else None
+    L.check("gstvd_gemm", lib.gstvd_gemm(C.byref(d), _stream()))
+    return C_out
+
+
+def _ln_desc(mode, dtype, M, H, gamma, beta, mean, rstd, eps, x=None, res=None, y=None, p_pre=0.0, p_post=0.0,
+             site_pre=0, site_post=0, rng=None, ids=None, segs=None, T=0, type_vocab=2, word=None, pos=None, tt=None,
+             tt_ext=None, loc=None, w_loc=None, b_loc=None):
+    d = L.LnDesc()
+    d.mode, d.dtype, d.M, d.H = mode, dtype, M, H
+    d.x, d.ldx = _p(x), (x.stride(-2) if x is not None else 0)
+    d.res, d.ldres = _p(res), (res.stride(-2) if res is not None else 0)
+    d.gamma, d.beta, d.eps = _p(gamma), _p(beta), eps
+    d.y, d.ldy = _p(y), (y.stride(-2) if y is not None else 0)
+    d.mean, d.rstd = _p(mean), _p(rstd)
+    d.p_pre, d.p_post, d.site_pre, d.site_post = p_pre, p_post, site_pre, site_post
+    d.rng = rng.ptr() if (rng is not None and (p_pre > 0 or p_post > 0)) else None
+    d.ids, d.segs, d.T, d.type_vocab = _p(ids), _p(segs), T, type_vocab
+    d.word, d.pos, d.tt, d.tt_ext = _p(word), _p(pos), _p(tt), _p(tt_ext)
+    d.loc, d.w_loc, d.b_loc = _p(loc), _p(w_loc), _p(b_loc)
+    return d
+
+
+def ln_fwd(**kw):
+    lib = L.load()
+    d = _ln_desc(**kw)
+    L.check("gstvd_ln_fwd", lib.gstvd_ln_fwd(C.byref(d), _stream()))
+
+
+def ln_bwd_blocks(M):
+    return int(L.load().gstvd_ln_bwd_blocks(M))
+
+
+def ln_bwd(fwd_kw, dy, partial, dres=None, dx=None, dword=None, dpos=None, dtt=None, dtt_ext=None):
+    lib = L.load()
+    b = L.LnBwdDesc()
+    b.f = _ln_desc(**fwd_kw)
+    b.dy, b.lddy = _p(dy), dy.stride(-2)
+    b.dres, b.lddres = _p(dres), (dres.stride(-2) if dres is not None else 0)
+    b.dx, b.lddx = _p(dx), (dx.stride(-2) if dx is not None else 0)
+    b.partial = _p(partial)
+    b.dword, b.dpos, b.dtt, b.dtt_ext = _p(dword), _p(dpos), _p(dtt), _p(dtt_ext)
+    L.check("gstvd_ln_bwd", lib.gstvd_ln_bwd(C.byref(b), _stream()))
+
+
+def colsum_partials(partial, nblk, nvec, H, out0, out1, out2, accumulate):
+    lib = L.load()
+    L.check("gstvd_colsum_partials", lib.gstvd_colsum_partials(_p(partial), nblk, nvec, H, _p(out0), _p(out1), _p(out2),
+                                                               int(accumulate), _stream()))
+
+
+def colsum(x, M, N, out, scratch, accumulate):
+    lib = L.load()
+    L.check("gstvd_colsum", lib.gstvd_colsum(_p(x), x.stride(-2), M, N, dt(x), _p(out), _p(scratch), scratch.numel(),
+                                             int(accumulate), _stream()))
+
+
+def locgrad(dh, loc, M, H, dw_loc, accumulate):
+    lib = L.load()
+    L.check("gstvd_locgrad", lib.gstvd_locgrad(_p(dh), dh.stride(-2), _p(loc), M, H, dt(dh), _p(dw_loc), int(accumulate),
+                                               _stream()))
+
+
+def attn_desc(Q, K, V, O, LSE, key_mask, B, nh, Lq, Lk, d, *, causal=False, mask_neg=-10000.0, scale=None, drop_p=0.0,
+              site=0, rng=None, ldq=None, ldk=None, ldv=None, ldo=None):
+    a = L.AttnDesc()
+    a.Q, a.K, a.V, a.O, a.LSE, a.key_mask = _p(Q), _p(K), _p(V), _p(O), _p(LSE), _p(key_mask)
+    a.ldq = Q.stride(-2) if ldq is None else ldq
+    a.ldk = K.stride(-2) if ldk is None else ldk
+    a.ldv = V.stride(-2) if ldv is None else ldv
+    a.ldo = O.stride(-2) if ldo is None else ldo
+    a.B, a.nh, a.Lq, a.Lk, a.d, a.causal, a.dtype = B, nh, Lq, Lk, d, int(causal), dt(Q)
+    a.mask_neg = mask_neg
+    a.scale = (1.0 / (d ** 0.5)) if scale is None else scale
+    a.dropout_p, a.site = drop_p, site
+    a.rng = rng.ptr() if (rng is not None and drop_p > 0) else None
+    return a
+
+
+def attn_fwd(a):
+    lib = L.load()
+    L.check("gstvd_attn_fwd", lib.gstvd_attn_fwd(C.byref(a), _stream()))
+
+
+def attn_bwd(a, dO, dQ, dK, dV, delta, lddo=None, lddq=None, lddk=None, lddv=None):
+    lib = L.load()
+    a.dO, a.dQ, a.dK, a.dV, a.delta = _p(dO), _p(dQ), _p(dK), _p(dV), _p(delta)
+    a.lddo = dO.stride(-2) if lddo is None else lddo
+    a.lddq = dQ.stride(-2) if lddq is None else lddq
+    a.lddk = dK.stride(-2) if lddk is None else lddk
+    a.lddv = dV.stride(-2) if lddv is None else lddv
+    L.check("gstvd_attn_bwd", lib.gstvd_attn_bwd(C.byref(a), _stream()))
+
+
+def ce_fwd(logits, labels, M, V, row_loss, lse, stats, ignore_index=0):
+    lib = L.load()
+    L.check("gstvd_ce_fwd", lib.gstvd_ce_fwd(_p(logits), logits.stride(-2), _p(labels), M, V, ignore_index, dt(logits),
+                                             _p(row_loss), _p(lse), _p(stats), _stream()))
+
+
+def ce_bwd(logits, labels, lse, stats, gscale, mean, M, V, dlogits, ignore_index=0):
+    lib = L.load()
+    L.check("gstvd_ce_bwd", lib.gstvd_ce_bwd(_p(logits), logits.stride(-2), _p(labels), _p(lse), _p(stats), _p(gscale),
+                                             int(mean), M, V, ignore_index, dt(logits), _p(dlogits), dlogits.stride(-2),
+                                             _stream()))
+
+
+def answer_scores(logits, lse, dec_ids, rows, U, scores):
+    lib = L.load()
+    L.check("gstvd_answer_scores", lib.gstvd_answer_scores(_p(logits), logits.stride(-2), _p(lse), _p(dec_ids), rows, U,
+                                                           dt(logits), _p(scores), _stream()))
+
+
+def cast(src, dst, n=None):
+    lib = L.load()
+    n = src.numel() if n is None else n
+    L.check("gstvd_cast", lib.gstvd_cast(_p(src), dt(src), _p(dst), dt(dst), n, _stream()))
+    return dst
+
+
+def scale_(x, factor):
+    lib = L.load()
+    L.check("gstvd_scale", lib.gstvd_scale(_p(x), _p(factor), x.numel(), _stream()))
+
+
+def dropout_mask(n, p, site, rng, device):
+    lib = L.load()
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    L.check("gstvd_dropout_mask", lib.gstvd_dropout_mask(_p(out), n, p, site, rng.ptr(), _stream()))
+    return out
+
+
+def adamw(param, grad, m, v, shadow, seg_end, hp, step, beta1=0.9, beta2=0.999, eps=1e-6, grad_scale=1.0):
+    lib = L.load()
+    L.check("gstvd_adamw", lib.gstvd_adamw(_p(param), _p(grad), _p(m), _p(v), _p(shadow), param.numel(), _p(seg_end), _p(hp),
+                                           seg_end.numel(), beta1, beta2, eps, _p(step), grad_scale, _stream()))

@@ -1,0 +1,182 @@
+/*
+ * gstvd_hip.h -- C ABI of the MI355X (gfx950) kernels behind the gst-visdial enc_dec_a hot path.
+ *
+ * The reference (gicheonkang/gst-visdial) has NO native/FFI boundary: its hot path is eager
+ * PyTorch inside models/vilbert_dialog.py, models/visual_dialog_{encoder,decoder,model}.py
+ * (SURVEY.md section 8b).  This header is therefore the build's own boundary; every entry
+ * point names the reference code it replaces.  Conventions:
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers unless noted;
+ *   - the caller owns every buffer (no allocation inside), passes the hipStream_t to launch on;
+ *   - return value: 0 = ok, <0 = invalid argument (GSTVD_E_*), >0 = hipError_t of the launch;
+ *   - re-entrant, no global mutable state; safe under hipGraph stream capture
+ *     (no sync / malloc / memcpy inside);
+ *   - dtype: GSTVD_F32 (exact-fp32 parity mode, f32-input MFMA) or GSTVD_BF16 (bf16 storage,
+ *     fp32 accumulate / statistics) -- the arithmetic type of activations;
+ *   - dropout is counter based: keep(e) = hash(rng[0] (seed), rng[1] (step offset), site, e);
+ *     `rng` points to two uint64 in device memory so a captured graph sees a fresh offset
+ *     per replay; backward regenerates the mask instead of storing it.
+ */
+#ifndef GSTVD_HIP_H
+#define GSTVD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* gstvd_stream_t; /* hipStream_t */
+
+enum { GSTVD_F32 = 0, GSTVD_BF16 = 1 };
+enum {
+  GSTVD_E_DTYPE = -1, GSTVD_E_SHAPE = -2, GSTVD_E_ALIGN = -3, GSTVD_E_NULL = -4, GSTVD_E_UNSUPPORTED = -5
+};
+
+/* ---- library info ----------------------------------------------------------------------- */
+int gstvd_abi_version(void);            /* bumps on any signature change */
+const char* gstvd_build_arch(void);     /* "gfx950" */
+
+/* ---- GEMM: every nn.Linear forward / dgrad / wgrad on the path ---------------------------
+ * C[m,n] = epi( alpha * sum_k A(m,k) * B(n,k) ),   batch = grid.z with element strides s*.
+ *   A(m,k) = a_kmajor ? A[k*lda + m] : A[m*lda + k];   B(n,k) = b_kmajor ? B[k*ldb + n] : B[n*ldb + k]
+ * forward  y = x W^T + b        : A=x,  B=W            (vilbert_dialog.py:381-383,417,446,459 ...)
+ * dgrad    dx = dy W            : A=dy, B=W  b_kmajor
+ * wgrad    dW = dy^T x          : A=dy a_kmajor, B=x b_kmajor, fp32 output, optional accumulate
+ * Epilogue flags (bitmask), applied in this order:
+ *   GSTVD_EPI_BIAS      += bias[n]                       (bias is always fp32)
+ *   GSTVD_EPI_ADD       += addend[m,n]                   (dtype_out; residual / grad accumulate)
+ *   GSTVD_EPI_GELU      aux[m,n] = v (pre-activation, dtype_in); v = gelu_erf(v)   (vilbert_dialog.py:115-121)
+ *   GSTVD_EPI_DGELU     v *= gelu_erf'(aux[m,n])
+ *   GSTVD_EPI_DROPOUT   v *= keep(site, (z*M+m)*N+n) / (1-p)      (VLFusion dropout, visual_dialog_model.py:133)
+ * Constraints: N % 4 == 0; row-major operands need K % (16/sizeof(T)) == 0 and 16-byte aligned rows;
+ * k-major operands need their M (resp. N) extent % (16/sizeof(T)) == 0.  M and the k extent of
+ * k-major operands are arbitrary (predicated / zero filled).
+ */
+enum { GSTVD_EPI_BIAS = 1, GSTVD_EPI_ADD = 2, GSTVD_EPI_GELU = 4, GSTVD_EPI_DGELU = 8, GSTVD_EPI_DROPOUT = 16 };
+
+typedef struct {
+  const void* A; const void* B; void* C;
+  const float* bias; const void* addend; void* aux;
+  int64_t M, N, K;
+  int64_t lda, ldb, ldc, ldadd, ldaux;
+  int64_t batch, sA, sB, sC, sAdd, sAux;
+  int32_t dtype_in, dtype_out, a_kmajor, b_kmajor, epilogue;
+  float alpha, dropout_p;
+  uint32_t site;
+  const uint64_t* rng;
+} gstvd_gemm_t;
+int gstvd_gemm(const gstvd_gemm_t* g, gstvd_stream_t s);
+
+/* ---- fused (bias-free) dropout + residual + LayerNorm, and the two embedding front ends -----
+ * mode GSTVD_LN_RESID : h = drop_pre(x) + res ; y = drop_post(LN(h))   (BertSelfOutput/BertOutput/
+ *        BertBiOutput, vilbert_dialog.py:416-420,458-462,735-742; HF BertSelfOutput/BertOutput)
+ * mode GSTVD_LN_EMBED : h = word[ids] + pos[t] + type(seg)             (BertEmbeddingsDialog, :324-352)
+ * mode GSTVD_LN_IMAGE : h = x + loc W_loc^T + b_loc                    (BertImageEmbeddings, :1420-1427)
+ * LayerNorm is the TF-style (x-u)/sqrt(var+eps) of vilbert_dialog.py:283-296.
+ * mean / rstd (fp32 [M]) are saved for backward.
+ */
+enum { GSTVD_LN_RESID = 0, GSTVD_LN_EMBED = 1, GSTVD_LN_IMAGE = 2 };
+
+typedef struct {
+  int32_t mode, dtype;
+  int64_t M, H;                 /* rows, hidden (H % 4 == 0, H <= 2048) */
+  const void* x; int64_t ldx;   /* RESID / IMAGE: [M,H] */
+  const void* res; int64_t ldres; /* RESID: residual or NULL */
+  const float* gamma; const float* beta; float eps;
+  void* y; int64_t ldy;
+  float* mean; float* rstd;
+  float p_pre, p_post; uint32_t site_pre, site_post; const uint64_t* rng;
+  /* EMBED */
+  const int64_t* ids; const int64_t* segs; /* [M]; segs may be NULL (=0) */
+  int64_t T; int32_t type_vocab;           /* position = row % T */
+  const float* word; const float* pos; const float* tt; const float* tt_ext; /* fp32 tables, row stride H */
+  /* IMAGE */
+  const float* loc; const float* w_loc; const float* b_loc; /* loc [M,5] fp32, w_loc [H,5], b_loc [H] */
+} gstvd_ln_t;
+int gstvd_ln_fwd(const gstvd_ln_t* p, gstvd_stream_t s);
+
+/* backward: dh = LN'(dy) ; dres = dh ; dx = drop_pre'(dh).
+ * partial: fp32 [nblk, 3, H] scratch (nblk = gstvd_ln_bwd_blocks(M)) receiving per-block column sums of
+ * (dy*xhat, dy, dx); reduce them with gstvd_colsum_partials.
+ * EMBED mode scatters dh into dword/dpos/dtt/dtt_ext (fp32, atomic add) instead of writing dres/dx. */
+typedef struct {
+  gstvd_ln_t f;                 /* the forward descriptor (y unused) */
+  const void* dy; int64_t lddy;
+  void* dres; int64_t lddres;   /* RESID: gradient wrt res (NULL allowed if res NULL); IMAGE: dh */
+  void* dx; int64_t lddx;       /* RESID: gradient wrt x (may alias dres when p_pre == 0) */
+  float* partial;
+  float* dword; float* dpos; float* dtt; float* dtt_ext; /* EMBED */
+} gstvd_ln_bwd_t;
+int64_t gstvd_ln_bwd_blocks(int64_t M);
+int gstvd_ln_bwd(const gstvd_ln_bwd_t* p, gstvd_stream_t s);
+
+/* out_j[c] (+)= sum_blk partial[blk, j, c]  for j in 0..nvec-1 ; out_j may be NULL (skipped) */
+int gstvd_colsum_partials(const float* partial, int64_t nblk, int64_t nvec, int64_t H,
+                          float* out0, float* out1, float* out2, int32_t accumulate, gstvd_stream_t s);
+
+/* out[c] (+)= sum_m x[m, c]   (bias gradients of QKV / FFN-up projections) */
+int gstvd_colsum(const void* x, int64_t ldx, int64_t M, int64_t N, int32_t dtype, float* out,
+                 float* scratch, int64_t scratch_elems, int32_t accumulate, gstvd_stream_t s);
+
+/* dW_loc[h, j] (+)= sum_m dh[m,h] * loc[m,j]   (image_location_embeddings.weight grad) */
+int gstvd_locgrad(const void* dh, int64_t lddh, const float* loc, int64_t M, int64_t H, int32_t dtype,
+                  float* dw_loc, int32_t accumulate, gstvd_stream_t s);
+
+/* ---- fused attention: softmax(Q K^T * scale + mask) V with dropout on the probabilities ------
+ * (BertSelfAttention / BertImageSelfAttention / BertBiAttention, vilbert_dialog.py:380-407,507-534,
+ *  646-712; HF 4.16.2 BertSelfAttention incl. the causal decoder mask and cross attention.)
+ * Element (b, i, h, c) of Q lives at Q[(b*Lq + i)*ldq + h*d + c]; K, V, O, dO, dQ, dK, dV alike, so the
+ * operands can be column slices of fused QKV buffers.
+ * additive mask(b, i, j) = (key_mask[b, j] != 0 && (!causal || j <= i)) ? 0 : mask_neg;
+ * LSE [B, nh, Lq] fp32 is saved by forward; backward recomputes P from it (nothing of size Lq x Lk is stored).
+ * d in {32, 64, 128}.
+ */
+typedef struct {
+  const void *Q, *K, *V; void* O; float* LSE;
+  const float* key_mask;            /* [B, Lk] 1/0, or NULL = all ones */
+  int64_t ldq, ldk, ldv, ldo;
+  int32_t B, nh, Lq, Lk, d, causal, dtype;
+  float mask_neg, scale, dropout_p; uint32_t site; const uint64_t* rng;
+  /* backward only */
+  const void* dO; int64_t lddo;
+  void *dQ, *dK, *dV; int64_t lddq, lddk, lddv;
+  float* delta;                      /* [B, nh, Lq] fp32 scratch: rowsum(dO * O) */
+} gstvd_attn_t;
+int gstvd_attn_fwd(const gstvd_attn_t* a, gstvd_stream_t s);
+int gstvd_attn_bwd(const gstvd_attn_t* a, gstvd_stream_t s);  /* dQ (+delta) then dK,dV */
+
+/* ---- LM head loss: CrossEntropyLoss(ignore_index) of visual_dialog_decoder.py:70-77 ----------
+ * logits [M, ldl >= V]; row_loss [M] (0 for ignored rows); stats[0] = sum of row losses,
+ * stats[1] = number of non-ignored rows (both fp32, zeroed by the call); lse [M] saved.
+ * mean loss = stats[0] / stats[1]. */
+int gstvd_ce_fwd(const void* logits, int64_t ldl, const int64_t* labels, int64_t M, int64_t V,
+                 int64_t ignore_index, int32_t dtype, float* row_loss, float* lse, float* stats,
+                 gstvd_stream_t s);
+/* dlogits[m, v] = (softmax - onehot) * gscale[0] / (mean ? stats[1] : 1) for kept rows, 0 otherwise;
+ * columns V..ldd-1 are zero filled (they are the zero padded vocabulary rows of the LM head). */
+int gstvd_ce_bwd(const void* logits, int64_t ldl, const int64_t* labels, const float* lse,
+                 const float* stats, const float* gscale, int32_t mean, int64_t M, int64_t V,
+                 int64_t ignore_index, int32_t dtype, void* dlogits, int64_t ldd, gstvd_stream_t s);
+/* evaluate_gen.py:94-106: score[m] = sum_u [tgt != 0] * (logits[m,u,tgt] - lse[m,u]) with tgt = ids shifted left */
+int gstvd_answer_scores(const void* logits, int64_t ldl, const float* lse, const int64_t* dec_ids,
+                        int64_t rows, int64_t U, int32_t dtype, float* scores, gstvd_stream_t s);
+
+/* ---- element-wise plumbing --------------------------------------------------------------------*/
+int gstvd_cast(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t n, gstvd_stream_t s);
+int gstvd_scale(float* x, const float* factor, int64_t n, gstvd_stream_t s);   /* x *= factor[0] */
+int gstvd_rng_advance(uint64_t* rng, gstvd_stream_t s);                        /* rng[1] += 1 */
+/* materialise a dropout mask (1/(1-p) or 0) for tests: out[e] for e in [0, n) */
+int gstvd_dropout_mask(float* out, int64_t n, float p, uint32_t site, const uint64_t* rng, gstvd_stream_t s);
+
+/* fused AdamW over flat fp32 buffers with pytorch_transformers-1.2.0 semantics (train_gen.py:16,247:
+ * eps inside sqrt(v)+eps, bias correction, decoupled decay applied after the update) and, optionally,
+ * refresh of the bf16 shadow weights in the same pass.  lr/wd are per-element-segment tables:
+ * seg_end[i] is the exclusive end offset of segment i; hp[2*i] = lr, hp[2*i+1] = weight decay. */
+int gstvd_adamw(float* param, const float* grad, float* m, float* v, void* shadow_bf16, int64_t n,
+                const int64_t* seg_end, const float* hp, int64_t nseg, float beta1, float beta2, float eps,
+                const float* step /* device scalar, 1-based */, float grad_scale, gstvd_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSTVD_HIP_H */

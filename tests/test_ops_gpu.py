@@ -1,0 +1,384 @@
+"""Per-kernel parity through the C ABI on a real MI355X: every HIP op against a plain PyTorch fp32
+reference of the same op (fp32 mode: tight tolerance; bf16 mode: tolerance of one bf16 rounding of the
+output scale).  Dropout is checked exactly by materialising the kernel's own counter-based mask."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def ops():
+    from gst_visdial_amd import ops as o
+    return o
+
+
+def tol(dtype):
+    return 2e-5 if dtype == torch.float32 else 1.2e-2
+
+
+def check(name, got, ref, dtype, mult=1.0):
+    got, ref = got.float(), ref.float()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), name + ": non-finite output"
+    scale = max(ref.abs().max().item(), 1e-6)
+    err = (got - ref).abs().max().item() / scale
+    assert err <= tol(dtype) * mult, "%s: rel-to-max error %.3e (scale %.3e, tol %.1e)" % (name, err, scale, tol(dtype) * mult)
+
+
+def rnd(*shape, dtype=torch.float32, seed=0, s=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * s).to(DEV).to(dtype)
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(200, 96, 64), (300, 256, 128), (111, 64, 320), (592, 1024, 256), (1024, 768, 192)])
+def test_gemm_forward_bias(dtype, M, N, K):
+    o = ops()
+    x, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, s=0.1)
+    b = rnd(N, seed=3)
+    y = torch.full((M, N), float("nan"), device=DEV, dtype=dtype)
+    o.gemm(x, w, y, M, N, K, bias=b)
+    check("gemm_nt", y, x.float() @ w.float().t() + b, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_asymmetric_identity(dtype):
+    """A = I with an asymmetric B catches transposed C writes (guide: always A=I-check with asymmetric B)."""
+    o = ops()
+    M = N = K = 64
+    a = torch.eye(M, device=DEV, dtype=dtype)
+    w = (torch.arange(N * K, device=DEV).float().reshape(N, K) % 13 - 6).to(dtype)   # exact small ints
+    y = torch.empty(M, N, device=DEV, dtype=dtype)
+    o.gemm(a, w, y, M, N, K)
+    assert torch.equal(y.float(), w.float().t())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(200, 64, 96), (300, 128, 256), (592, 256, 1024)])
+def test_gemm_dgrad_kmajor_b(dtype, M, N, K):
+    """dx[M,N] = dy[M,K] @ W[K,N]  with W stored [K,N] (k-major B)."""
+    o = ops()
+    dy, w = rnd(M, K, dtype=dtype, seed=4), rnd(K, N, dtype=dtype, seed=5, s=0.1)
+    r = rnd(M, N, dtype=dtype, seed=6)
+    dx = torch.empty(M, N, device=DEV, dtype=dtype)
+    o.gemm(dy, w, dx, M, N, K, b_km=True, addend=r)
+    check("gemm_nn_add", dx, dy.float() @ w.float() + r.float(), dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,N,K", [(111, 64, 96), (300, 128, 256), (4100, 256, 128)])
+def test_gemm_wgrad_accumulate(dtype, rows, N, K):
+    """dW[N,K] (+)= dy[rows,N]^T @ x[rows,K]; fp32 output, both operands k-major, contraction not a tile multiple."""
+    o = ops()
+    dy, x = rnd(rows, N, dtype=dtype, seed=7), rnd(rows, K, dtype=dtype, seed=8)
+    dw = rnd(N, K, seed=9)
+    ref = dw + dy.float().t() @ x.float()
+    o.gemm(dy, x, dw, N, K, rows, a_km=True, b_km=True, addend=dw)
+    check("gemm_tn_acc", dw, ref, dtype, mult=2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_gelu_epilogues(dtype):
+    o = ops()
+    M, N, K = 150, 128, 64
+    x, w, b = rnd(M, K, dtype=dtype, seed=10), rnd(N, K, dtype=dtype, seed=11, s=0.2), rnd(N, seed=12)
+    u = torch.empty(M, N, device=DEV, dtype=dtype)
+    a = torch.empty(M, N, device=DEV, dtype=dtype)
+    o.gemm(x, w, a, M, N, K, bias=b, aux=u, epi=o.EPI_GELU)
+    uref = x.float() @ w.float().t() + b
+    check("gelu_pre", u, uref, dtype)
+    check("gelu_out", a, torch.nn.functional.gelu(uref), dtype)
+    # dgelu: d_u = (d_a @ W2) * gelu'(u)
+    da, w2 = rnd(M, K, dtype=dtype, seed=13), rnd(K, N, dtype=dtype, seed=14, s=0.2)
+    du = torch.empty(M, N, device=DEV, dtype=dtype)
+    o.gemm(da, w2, du, M, N, K, b_km=True, aux=u, epi=o.EPI_DGELU)
+    uu = u.float().clone().requires_grad_(True)
+    torch.nn.functional.gelu(uu).backward(da.float() @ w2.float())
+    check("dgelu", du, uu.grad, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_batched_and_dropout(dtype):
+    o = ops()
+    Bn, M, N, K = 3, 37, 64, 96
+    x, w = rnd(Bn, M, K, dtype=dtype, seed=15), rnd(N, K, dtype=dtype, seed=16, s=0.1)
+    b = rnd(N, seed=17)
+    S = M + 11
+    y = torch.zeros(Bn, S, N, device=DEV, dtype=dtype)
+    rng = o.Rng(DEV, seed=1234)
+    o.gemm(x, w, y[:, 5:], M, N, K, bias=b, batch=Bn, sA=M * K, sC=S * N, lda=K, ldc=N, drop_p=0.1, site=7, rng=rng)
+    mask = o.dropout_mask(Bn * M * N, 0.1, 7, rng, DEV).view(Bn, M, N)
+    keep = (mask != 0).float().mean().item()
+    assert abs(keep - 0.9) < 0.02, keep
+    assert torch.all((mask == 0) | ((mask - 1 / 0.9).abs() < 1e-6))
+    ref = (x.float() @ w.float().t() + b) * mask
+    check("gemm_batched_dropout", y[:, 5:5 + M], ref, dtype)
+    assert torch.all(y[:, :5] == 0) and torch.all(y[:, 5 + M:] == 0)
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm
+def ln_ref(h, gamma, beta, eps=1e-12):
+    u = h.mean(-1, keepdim=True)
+    s = (h - u).pow(2).mean(-1, keepdim=True)
+    return gamma * ((h - u) / torch.sqrt(s + eps)) + beta
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,H", [(70, 64), (45, 96), (130, 768), (50, 1024)])
+@pytest.mark.parametrize("p", [0.0, 0.3])
+def test_ln_resid_fwd_bwd(dtype, M, H, p):
+    o = ops()
+    x, res = rnd(M, H, dtype=dtype, seed=20), rnd(M, H, dtype=dtype, seed=21)
+    gamma, beta = 1 + 0.1 * rnd(H, seed=22), 0.1 * rnd(H, seed=23)
+    dy = rnd(M, H, dtype=dtype, seed=24)
+    rng = o.Rng(DEV, seed=99)
+    y = torch.empty(M, H, device=DEV, dtype=dtype)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    kw = dict(mode=o.LN_RESID, dtype=o.dt(x), M=M, H=H, gamma=gamma, beta=beta, mean=mean, rstd=rstd, eps=1e-12,
+              x=x, res=res, y=y, p_pre=p, site_pre=3, rng=rng)
+    o.ln_fwd(**kw)
+    mask = o.dropout_mask(M * H, p, 3, rng, DEV).view(M, H) if p > 0 else torch.ones(M, H, device=DEV)
+    xr, rr = x.float().requires_grad_(True), res.float().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    yref = ln_ref(xr * mask + rr, gr, br)
+    check("ln_fwd", y, yref, dtype)
+    yref.backward(dy.float())
+    nblk = o.ln_bwd_blocks(M)
+    partial = torch.empty(nblk, 3, H, device=DEV)
+    dres = torch.empty(M, H, device=DEV, dtype=dtype)
+    dx = torch.empty(M, H, device=DEV, dtype=dtype) if p > 0 else dres
+    o.ln_bwd(kw, dy, partial, dres=dres, dx=dx)
+    dg, db, dbias = torch.zeros(H, device=DEV), torch.ones(H, device=DEV), torch.empty(H, device=DEV)
+    o.colsum_partials(partial, nblk, 3, H, dg, db, dbias, accumulate=False)
+    check("ln_dres", dres, rr.grad, dtype, 2.0)
+    check("ln_dx", dx, xr.grad, dtype, 2.0)
+    check("ln_dgamma", dg, gr.grad, dtype, 3.0)
+    check("ln_dbeta", db, br.grad, dtype, 3.0)
+    check("ln_dbias", dbias, xr.grad.sum(0), dtype, 3.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_ln_embed_fwd_bwd(dtype):
+    o = ops()
+    Bn, T, H, V = 3, 24, 64, 50
+    M = Bn * T
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(0, V, (Bn, T), generator=g).to(DEV)
+    segs = torch.randint(0, 4, (Bn, T), generator=g).to(DEV)      # includes extension ids 2,3
+    word, pos, tt, tte = rnd(V, H, seed=30), rnd(40, H, seed=31), rnd(2, H, seed=32), rnd(10, H, seed=33)
+    gamma, beta = 1 + 0.1 * rnd(H, seed=34), 0.1 * rnd(H, seed=35)
+    y = torch.empty(M, H, device=DEV, dtype=dtype)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    rng = o.Rng(DEV, seed=5)
+    kw = dict(mode=o.LN_EMBED, dtype=o.dt(y), M=M, H=H, gamma=gamma, beta=beta, mean=mean, rstd=rstd, eps=1e-12, y=y,
+              ids=ids.view(-1), segs=segs.view(-1), T=T, type_vocab=2, word=word, pos=pos, tt=tt, tt_ext=tte,
+              p_post=0.3, site_post=11, rng=rng)
+    o.ln_fwd(**kw)
+    mask = o.dropout_mask(M * H, 0.3, 11, rng, DEV).view(M, H)
+    ws = [t.clone().requires_grad_(True) for t in (word, pos, tt, tte, gamma, beta)]
+    typ = torch.where((segs < 2)[..., None], ws[2][segs.clamp(max=1)], ws[3][(segs - 2).clamp(min=0)])
+    h = ws[0][ids] + ws[1][:T][None] + typ
+    yref = ln_ref(h, ws[4], ws[5]).view(M, H) * mask
+    check("embed_fwd", y, yref, dtype)
+    dy = rnd(M, H, dtype=dtype, seed=36)
+    yref.backward(dy.float())
+    nblk = o.ln_bwd_blocks(M)
+    partial = torch.empty(nblk, 3, H, device=DEV)
+    dws = [torch.zeros_like(t) for t in (word, pos, tt, tte)]
+    o.ln_bwd(kw, dy, partial, dword=dws[0], dpos=dws[1], dtt=dws[2], dtt_ext=dws[3])
+    dg, db = torch.empty(H, device=DEV), torch.empty(H, device=DEV)
+    o.colsum_partials(partial, nblk, 2, H, dg, db, None, accumulate=False)
+    for name, got, ref in zip(("dword", "dpos", "dtt", "dtt_ext"), dws, ws[:4]):
+        check("embed_" + name, got, ref.grad, dtype, 3.0)
+    check("embed_dgamma", dg, ws[4].grad, dtype, 3.0)
+    check("embed_dbeta", db, ws[5].grad, dtype, 3.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_ln_image_fwd_bwd(dtype):
+    o = ops()
+    M, H = 21, 96
+    x = rnd(M, H, dtype=dtype, seed=40)
+    loc = torch.rand(M, 5, device=DEV)
+    wl, bl = rnd(H, 5, seed=41, s=0.3), rnd(H, seed=42, s=0.1)
+    gamma, beta = 1 + 0.1 * rnd(H, seed=43), 0.1 * rnd(H, seed=44)
+    y = torch.empty(M, H, device=DEV, dtype=dtype)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    kw = dict(mode=o.LN_IMAGE, dtype=o.dt(x), M=M, H=H, gamma=gamma, beta=beta, mean=mean, rstd=rstd, eps=1e-12,
+              x=x, y=y, loc=loc, w_loc=wl, b_loc=bl)
+    o.ln_fwd(**kw)
+    xr, wr, br = x.float().requires_grad_(True), wl.clone().requires_grad_(True), bl.clone().requires_grad_(True)
+    yref = ln_ref(xr + loc @ wr.t() + br, gamma, beta)
+    check("image_fwd", y, yref, dtype)
+    dy = rnd(M, H, dtype=dtype, seed=45)
+    yref.backward(dy.float())
+    nblk = o.ln_bwd_blocks(M)
+    partial = torch.empty(nblk, 3, H, device=DEV)
+    dh = torch.empty(M, H, device=DEV, dtype=dtype)
+    o.ln_bwd(kw, dy, partial, dres=dh)
+    dbl = torch.empty(H, device=DEV)
+    o.colsum_partials(partial, nblk, 3, H, None, None, dbl, accumulate=False)
+    check("image_dh", dh, xr.grad, dtype, 2.0)
+    check("image_dbloc", dbl, br.grad, dtype, 3.0)
+    dwl = torch.empty(H, 5, device=DEV)
+    o.locgrad(dh, loc, M, H, dwl, accumulate=False)
+    check("image_dwloc", dwl, wr.grad, dtype, 3.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_colsum(dtype):
+    o = ops()
+    M, N = 333, 2304
+    x = rnd(M, N, dtype=dtype, seed=50)
+    out = torch.ones(N, device=DEV)
+    scratch = torch.empty(((M + 63) // 64) * N, device=DEV)
+    o.colsum(x, M, N, out, scratch, accumulate=True)
+    check("colsum", out, 1 + x.float().sum(0), dtype)
+
+
+# ------------------------------------------------------------------------------------------ attention
+def attn_ref(q, k, v, key_mask, causal, neg, scale, dmask):
+    s = torch.einsum("bqhd,bkhd->bhqk", q, k) * scale
+    Lq, Lk = q.shape[1], k.shape[1]
+    allowed = (key_mask != 0)[:, None, None, :].expand(-1, 1, Lq, -1)
+    if causal:
+        i = torch.arange(Lq, device=q.device)[:, None]
+        j = torch.arange(Lk, device=q.device)[None, :]
+        allowed = allowed & (j <= i)[None, None]
+    s = s + torch.where(allowed, torch.zeros((), device=q.device), torch.full((), neg, device=q.device))
+    p = torch.softmax(s, -1)
+    lse = torch.logsumexp(s, -1)
+    if dmask is not None:
+        p = p * dmask
+    return torch.einsum("bhqk,bkhd->bqhd", p, v), lse
+
+
+ATTN_CASES = [
+    # B, nh, Lq, Lk, d, causal, neg, p, fused
+    (2, 3, 40, 70, 32, False, -10000.0, 0.0, False),
+    (2, 2, 24, 24, 32, False, -10000.0, 0.1, True),     # tiny text self-attention
+    (1, 12, 256, 256, 64, False, -10000.0, 0.1, True),  # text self-attention, full size
+    (2, 8, 37, 37, 128, False, -10000.0, 0.1, True),    # vision self-attention
+    (2, 8, 256, 37, 128, False, -10000.0, 0.1, False),  # co-attention: text queries, vision keys
+    (2, 8, 37, 256, 128, False, -10000.0, 0.1, False),  # co-attention: vision queries, text keys
+    (3, 12, 25, 25, 64, True, -10000.0, 0.1, True),     # decoder causal self-attention
+    (2, 12, 25, 293, 64, False, -1e9, 0.1, False),      # decoder cross-attention
+    (2, 2, 9, 31, 32, True, -10000.0, 0.0, False),      # ragged tiny
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", ATTN_CASES)
+def test_attention_fwd_bwd(dtype, case):
+    o = ops()
+    Bn, nh, Lq, Lk, d, causal, neg, p, fused = case
+    H = nh * d
+    if fused:
+        qkv = rnd(Bn * Lq, 3 * H, dtype=dtype, seed=60)
+        Q, K, V = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+    else:
+        Q, K, V = rnd(Bn * Lq, H, dtype=dtype, seed=61), rnd(Bn * Lk, H, dtype=dtype, seed=62), rnd(Bn * Lk, H, dtype=dtype, seed=63)
+    km = torch.ones(Bn, Lk, device=DEV)
+    km[0, Lk - Lk // 3:] = 0
+    if Bn > 1:
+        km[1, Lk // 2] = 0
+    O = torch.full((Bn * Lq, H), float("nan"), device=DEV, dtype=dtype)
+    LSE = torch.empty(Bn, nh, Lq, device=DEV)
+    rng = o.Rng(DEV, seed=77)
+    a = o.attn_desc(Q, K, V, O, LSE, km, Bn, nh, Lq, Lk, d, causal=causal, mask_neg=neg, drop_p=p, site=21, rng=rng)
+    o.attn_fwd(a)
+    Lkp = (Lk + 3) // 4 * 4
+    dmask = None
+    if p > 0:
+        dmask = o.dropout_mask(Bn * nh * Lq * Lkp, p, 21, rng, DEV).view(Bn, nh, Lq, Lkp)[..., :Lk]
+    qr = Q.float().reshape(Bn, Lq, nh, d).clone().requires_grad_(True)
+    kr = K.float().reshape(Bn, Lk, nh, d).clone().requires_grad_(True)
+    vr = V.float().reshape(Bn, Lk, nh, d).clone().requires_grad_(True)
+    oref, lse_ref = attn_ref(qr, kr, vr, km, causal, neg, 1.0 / math.sqrt(d), dmask)
+    check("attn_out", O.view(Bn, Lq, nh, d), oref, dtype, 2.0)
+    check("attn_lse", LSE, lse_ref, dtype, 2.0)
+    dO = rnd(Bn * Lq, H, dtype=dtype, seed=64)
+    oref.backward(dO.float().view(Bn, Lq, nh, d))
+    if fused:
+        dqkv = torch.full_like(qkv, float("nan"))
+        dQ, dK, dV = dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:]
+    else:
+        dQ, dK, dV = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
+    delta = torch.empty(Bn, nh, Lq, device=DEV)
+    o.attn_bwd(a, dO, dQ, dK, dV, delta)
+    check("attn_dq", dQ.reshape(Bn, Lq, nh, d), qr.grad, dtype, 4.0)
+    check("attn_dk", dK.reshape(Bn, Lk, nh, d), kr.grad, dtype, 4.0)
+    check("attn_dv", dV.reshape(Bn, Lk, nh, d), vr.grad, dtype, 4.0)
+
+
+# ------------------------------------------------------------------------------------------ loss & misc
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_cross_entropy_fwd_bwd_and_scores(dtype):
+    o = ops()
+    rows, U, V, ld = 6, 9, 322, 384
+    M = rows * U
+    logits = torch.zeros(M, ld, device=DEV, dtype=dtype)
+    logits[:, :V] = rnd(M, V, dtype=dtype, seed=70, s=2.0)
+    g = torch.Generator().manual_seed(9)
+    labels = torch.randint(1, V, (M,), generator=g).to(DEV)
+    labels[::3] = 0
+    row_loss, lse, stats = torch.empty(M, device=DEV), torch.empty(M, device=DEV), torch.empty(2, device=DEV)
+    o.ce_fwd(logits, labels, M, V, row_loss, lse, stats)
+    lr = logits[:, :V].float().requires_grad_(True)
+    ref_none = torch.nn.functional.cross_entropy(lr, labels, ignore_index=0, reduction="none")
+    ref_mean = torch.nn.functional.cross_entropy(lr, labels, ignore_index=0)
+    check("ce_rows", row_loss, ref_none, torch.float32, 5.0)
+    assert abs((stats[0] / stats[1]).item() - ref_mean.item()) < 1e-4 * max(1.0, abs(ref_mean.item()))
+    assert stats[1].item() == (labels != 0).sum().item()
+    ref_mean.backward()
+    dl = torch.full((M, ld), float("nan"), device=DEV, dtype=dtype)
+    gs = torch.ones(1, device=DEV)
+    o.ce_bwd(logits, labels, lse, stats, gs, True, M, V, dl)
+    check("ce_dlogits", dl[:, :V], lr.grad, dtype, 2.0)
+    assert torch.all(dl[:, V:] == 0)
+    ids = torch.randint(1, V, (rows, U), generator=g).to(DEV)
+    ids[:, 6:] = 0
+    scores = torch.empty(rows, device=DEV)
+    o.answer_scores(logits, lse, ids, rows, U, scores)
+    lp = torch.log_softmax(logits[:, :V].float(), -1).view(rows, U, V)
+    tgt = torch.zeros_like(ids)
+    tgt[:, :-1] = ids[:, 1:]
+    ref = (torch.gather(lp, -1, tgt[..., None]).squeeze(-1) * (tgt != 0).float()).sum(-1)
+    check("answer_scores", scores, ref, torch.float32, 10.0)
+
+
+def test_cast_roundtrip_and_adamw():
+    o = ops()
+    n = 5003
+    x = rnd(n + 5, seed=80)[:n + 5]
+    xb = torch.empty(n, device=DEV, dtype=torch.bfloat16)
+    o.cast(x[:n], xb)
+    assert torch.equal(xb, x[:n].to(torch.bfloat16))
+    # AdamW, pytorch_transformers 1.2.0 semantics
+    p0, g0 = rnd(n, seed=81), rnd(n, seed=82, s=0.1)
+    m0, v0 = rnd(n, seed=83, s=0.01), rnd(n, seed=84, s=0.01).abs()
+    p, m, v = p0.clone(), m0.clone(), v0.clone()
+    shadow = torch.empty(n, device=DEV, dtype=torch.bfloat16)
+    seg_end = torch.tensor([1000, 3001, n], device=DEV)
+    hp = torch.tensor([2e-5, 0.01, 1e-3, 0.0, 5e-4, 0.1], device=DEV)
+    step = torch.tensor([3.0], device=DEV)
+    o.adamw(p, g0, m, v, shadow, seg_end, hp, step)
+    lr = torch.empty(n, device=DEV)
+    wd = torch.empty(n, device=DEV)
+    for (a, b), l_, w_ in zip(((0, 1000), (1000, 3001), (3001, n)), (2e-5, 1e-3, 5e-4), (0.01, 0.0, 0.1)):
+        lr[a:b], wd[a:b] = l_, w_
+    mr = m0 * 0.9 + 0.1 * g0
+    vr = v0 * 0.999 + 0.001 * g0 * g0
+    ss = lr * math.sqrt(1 - 0.999 ** 3) / (1 - 0.9 ** 3)
+    pr = p0 - ss * mr / (vr.sqrt() + 1e-6)
+    pr = pr - lr * wd * pr
+    check("adamw_p", p, pr, torch.float32, 5.0)
+    check("adamw_m", m, mr, torch.float32)
+    check("adamw_v", v, vr, torch.float32)
+    assert torch.equal(shadow, p.to(torch.bfloat16))
