@@ -69,6 +69,7 @@ SIGNATURES = {
     "gstvd_ce_fwd": (_i32, [_vp, _i64, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
     "gstvd_ce_bwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _i32, _vp, _i64, _vp]),
     "gstvd_answer_scores": (_i32, [_vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _vp]),
+    "gstvd_vl_split": (_i32, [_vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _f32, _u32, _u32, _vp, _vp]),
     "gstvd_cast": (_i32, [_vp, _i32, _vp, _i32, _i64, _vp]),
     "gstvd_scale": (_i32, [_vp, _vp, _i64, _vp]),
     "gstvd_rng_advance": (_i32, [_vp, _vp]),

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const T* logits, int64_t ld
   }
 }
 
-// stats[0] = sum(row_loss), stats[1] = #(label != ignore); single block, fixed order => deterministic
+// stats[0] = sum(row_loss), stats[1] = #(label != ignore), stats[2] = mean; single block, fixed order => deterministic
 __global__ __launch_bounds__(256) void ce_reduce_kernel(const float* row_loss, const int64_t* labels, int64_t M,
                                                         int64_t ignore, float* stats) {
   __shared__ float red[4];
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void ce_reduce_kernel(const float* row_loss, c
   }
   s = block_reduce(s, red, false);
   n = block_reduce(n, red, false);
-  if (threadIdx.x == 0) { stats[0] = s; stats[1] = n; }
+  if (threadIdx.x == 0) { stats[0] = s; stats[1] = n; stats[2] = s / n; }
 }
 
 template <typename T>
@@ -145,7 +145,35 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* param, const float* g
   }
 }
 
+// backward of VLFusion's concat + dropout (visual_dialog_model.py:132-133): split d_enc[B, R+T, H] into the
+// vision rows [B*R, H] and the text rows [B*T, H], re-applying each half's dropout mask
+template <typename T>
+__global__ __launch_bounds__(256) void vl_split_kernel(const T* d, int64_t B, int64_t R, int64_t Tt, int64_t H, T* dv, T* dt_,
+                                                       float p, uint32_t site_v, uint32_t site_t, const uint64_t* rng) {
+  const DropKey kv = make_drop(p, site_v, rng), kt = make_drop(p, site_t, rng);
+  const int64_t S = R + Tt, H4 = H / 4;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * S * H4) return;
+  const int64_t c = (i % H4) * 4, row = i / H4, b = row / S, r = row % S;
+  f32x4 v = ld4(d + row * H + c);
+  if (r < R) { const int64_t o = (b * R + r) * H + c; st4(dv + o, v * drop_factor4(kv, (uint64_t)o)); }
+  else { const int64_t o = (b * Tt + (r - R)) * H + c; st4(dt_ + o, v * drop_factor4(kt, (uint64_t)o)); }
+}
+
 // ---- C ABI ----------------------------------------------------------------------------------------------
+extern "C" int gstvd_vl_split(const void* d_enc, int64_t B, int64_t R, int64_t T, int64_t H, int32_t dtype, void* d_v, void* d_t,
+                              float p, uint32_t site_v, uint32_t site_t, const uint64_t* rng, gstvd_stream_t stream) {
+  if (!d_enc || !d_v || !d_t) return GSTVD_E_NULL;
+  if (B <= 0 || R <= 0 || T <= 0 || H <= 0 || (H % 4)) return GSTVD_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)((B * (R + T) * (H / 4) + 255) / 256));
+  if (dtype == GSTVD_BF16) hipLaunchKernelGGL(vl_split_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)d_enc, B, R, T, H, (bf16*)d_v, (bf16*)d_t, p, site_v, site_t, rng);
+  else if (dtype == GSTVD_F32) hipLaunchKernelGGL(vl_split_kernel<float>, grid, dim3(256), 0, s, (const float*)d_enc, B, R, T, H, (float*)d_v, (float*)d_t, p, site_v, site_t, rng);
+  else return GSTVD_E_DTYPE;
+  GSTVD_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int gstvd_abi_version(void) { return 1; }
 extern "C" const char* gstvd_build_arch(void) { return "gfx950"; }
 

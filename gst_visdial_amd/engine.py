@@ -1,0 +1,760 @@
+"""Execution engine of the enc_dec_a hot path on one MI355X.
+
+Replaces, for the modules of `modules.py`, the eager PyTorch arithmetic of
+    models/vilbert_dialog.py:324-912,1325-1427   (embeddings, two-stream encoder schedule)
+    models/visual_dialog_model.py:24-72,123-135 (glue, VLFusion)
+    models/visual_dialog_decoder.py:33-86,219-339 + transformers-4.16.2 BertEncoder (decoder, LM head, CE)
+and autograd's backward of all of it (train_gen.py:324) by a fixed schedule of HIP kernels called through
+the C ABI (`ops`).  Design points:
+
+  * parameters live in ONE flat fp32 buffer `P` (forward order), gradients in one flat fp32 buffer `G`,
+    bf16 shadow weights (throughput mode) in one flat bf16 buffer `S`; the nn.Parameters are views.
+    Q/K/V (and the co-attention / cross-attention K,V of all decoder layers) are laid out contiguously
+    so each projection group is ONE GEMM, and a data-parallel all-reduce is a handful of large slices;
+  * activations come from a bump arena that is rewound every step -> static addresses (hipGraph friendly),
+    no allocator traffic; nothing of size [Lq, Lk] is ever stored (attention saves only LSE);
+  * forward records a tape of backward closures; backward replays it in reverse.  Residual gradients are
+    accumulated in the dgrad GEMM epilogue, GELU' in the dgrad epilogue, bias gradients come out of the
+    LayerNorm backward partial sums; dropout masks are regenerated from (seed, step, site, index);
+  * the 42 parameters that get no gradient in enc_dec mode (poolers, cls heads, q_dense*, sep_embeddings;
+    models/vilbert_dialog.py:1400-1401,1482-1487) are never touched: their forward is dead compute in the
+    reference and skipping it changes no output.
+
+Numerics: precision 'fp32' runs every GEMM on the exact-fp32 MFMA (parity gate: logits within 1e-4 of the
+oracle); 'bf16' stores activations/weights in bf16 with fp32 accumulation and fp32 LN/softmax/CE statistics.
+"""
+import torch
+
+from . import ops
+from .config import encoder_schedule
+from ._lib import GstvdError, EPI_GELU, EPI_DGELU, LN_RESID, LN_EMBED, LN_IMAGE
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class Act(object):
+    """An activation [M, N] in the arena plus (during backward) its gradient."""
+    __slots__ = ("t", "g", "M", "N", "gelu_aux", "bias_done")
+
+    def __init__(self, t, M, N):
+        self.t, self.g, self.M, self.N = t, None, M, N
+        self.gelu_aux, self.bias_done = None, False
+
+
+class Arena(object):
+    """Bump allocator over large device chunks; `reset()` rewinds, so a fixed call sequence gets fixed addresses."""
+
+    def __init__(self, device, chunk_bytes=1 << 28):
+        self.device, self.chunk_bytes = device, chunk_bytes
+        self.chunks, self.ci, self.off = [], 0, 0
+        self.high = 0
+
+    def reset(self):
+        self.ci, self.off = 0, 0
+
+    _ESZ = {torch.float32: 4, torch.bfloat16: 2, torch.int64: 8, torch.uint8: 1, torch.int32: 4}
+
+    def alloc(self, numel, dtype):
+        nbytes = _round_up(numel * self._ESZ[dtype], 256)
+        while True:
+            if self.ci >= len(self.chunks):
+                self.chunks.append(torch.empty(max(self.chunk_bytes, nbytes), dtype=torch.uint8, device=self.device))
+            c = self.chunks[self.ci]
+            if self.off + nbytes <= c.numel():
+                out = c[self.off:self.off + nbytes].view(dtype)[:numel]
+                self.off += nbytes
+                return out
+            self.ci, self.off = self.ci + 1, 0
+
+
+class FlatParams(object):
+    """Flat storage plan.  `slots[name] = (offset, shape)` are engine views (possibly fused groups of several
+    nn.Parameters); every live nn.Parameter becomes a view of `P` and its `.grad` a view of `G`."""
+
+    def __init__(self, model, precision):
+        enc_cfg, dec_cfg = model.encoder.config, model.decoder.config
+        bert = model.encoder.bert_pretrained.bert
+        gen = model.decoder.decoder
+        self.slots, self.items, self.pads = {}, [], []
+        self.placed = {}
+        self.off = 0
+        H, Hv, Hb = enc_cfg.hidden_size, enc_cfg.v_hidden_size, enc_cfg.bi_hidden_size
+        V = dec_cfg.vocab_size
+        self.Vp = _round_up(V, 64)
+        lm_w = gen.lm_head.decoder.weight
+
+        def place(name, params, shape=None, pad_rows_to=None):
+            """Lay `params` out back to back under one fused slot `name`."""
+            self.off = _round_up(self.off, 64)
+            start = self.off
+            for p in params:
+                if id(p) in self.placed:
+                    raise GstvdError("parameter shared between two fused groups: " + name)
+                self.placed[id(p)] = self.off
+                self.items.append((p, self.off))
+                self.off += p.numel()
+            if pad_rows_to is not None:
+                cols = params[0].shape[1] if params[0].dim() == 2 else 1
+                want = pad_rows_to * cols
+                self.pads.append((self.off, start + want))
+                self.off = start + want
+            n = self.off - start
+            if shape is None:
+                shape = tuple(params[0].shape) if len(params) == 1 and pad_rows_to is None else (n,)
+            self.slots[name] = (start, shape)
+
+        def emb(prefix, mod):
+            w = mod.word_embeddings.weight
+            place(prefix + ".word", [w], shape=(self.Vp if w is lm_w else w.shape[0], w.shape[1]),
+                  pad_rows_to=self.Vp if w is lm_w else None)
+            place(prefix + ".pos", [mod.position_embeddings.weight])
+            place(prefix + ".tt", [mod.token_type_embeddings.weight])
+            place(prefix + ".tte", [mod.token_type_embeddings_extension.weight])
+            place(prefix + ".ln.w", [mod.LayerNorm.weight])
+            place(prefix + ".ln.b", [mod.LayerNorm.bias])
+
+        def attn_out_ffn(p, lay, hid, inter):
+            place(p + ".ao.w", [lay.attention.output.dense.weight]); place(p + ".ao.b", [lay.attention.output.dense.bias])
+            place(p + ".ln1.w", [lay.attention.output.LayerNorm.weight]); place(p + ".ln1.b", [lay.attention.output.LayerNorm.bias])
+
+        def ffn(p, inter_mod, out_mod, tag_i, tag_o, tag_ln):
+            place(p + tag_i + ".w", [inter_mod.dense.weight]); place(p + tag_i + ".b", [inter_mod.dense.bias])
+            place(p + tag_o + ".w", [out_mod.dense.weight]); place(p + tag_o + ".b", [out_mod.dense.bias])
+            place(p + tag_ln + ".w", [out_mod.LayerNorm.weight]); place(p + tag_ln + ".b", [out_mod.LayerNorm.bias])
+
+        def qkv(p, tag, q, k, v, hid_out, hid_in):
+            place(p + tag + ".w", [q.weight, k.weight, v.weight], shape=(3 * hid_out, hid_in))
+            place(p + tag + ".b", [q.bias, k.bias, v.bias], shape=(3 * hid_out,))
+
+        def bert_layer(p, lay, hid, inter):
+            s = lay.attention.self
+            qkv(p, ".qkv", s.query, s.key, s.value, hid, hid)
+            attn_out_ffn(p, lay, hid, inter)
+            ffn(p, lay.intermediate, lay.output, ".fi", ".fo", ".ln2")
+
+        self.enc_emb = bert.embeddings
+        self.dec_emb = gen.bert.embeddings
+        emb("emb", self.enc_emb)
+        ve = bert.v_embeddings
+        place("vemb.img.w", [ve.image_embeddings.weight]); place("vemb.img.b", [ve.image_embeddings.bias])
+        place("vemb.loc.w", [ve.image_location_embeddings.weight]); place("vemb.loc.b", [ve.image_location_embeddings.bias])
+        place("vemb.ln.w", [ve.LayerNorm.weight]); place("vemb.ln.b", [ve.LayerNorm.bias])
+        self.marks = {}
+        for kind, i in encoder_schedule(enc_cfg):
+            self.marks[(kind, i)] = _round_up(self.off, 64)
+            if kind == "t":
+                bert_layer("t%d" % i, bert.encoder.layer[i], H, enc_cfg.intermediate_size)
+            elif kind == "v":
+                bert_layer("v%d" % i, bert.encoder.v_layer[i], Hv, enc_cfg.v_intermediate_size)
+            else:
+                c, p = bert.encoder.c_layer[i], "c%d" % i
+                b = c.biattention
+                qkv(p, ".qkv1", b.query1, b.key1, b.value1, Hb, Hv)
+                qkv(p, ".qkv2", b.query2, b.key2, b.value2, Hb, H)
+                o = c.biOutput
+                place(p + ".d1.w", [o.dense1.weight]); place(p + ".d1.b", [o.dense1.bias])
+                place(p + ".ln1.w", [o.LayerNorm1.weight]); place(p + ".ln1.b", [o.LayerNorm1.bias])
+                place(p + ".d2.w", [o.dense2.weight]); place(p + ".d2.b", [o.dense2.bias])
+                place(p + ".ln2.w", [o.LayerNorm2.weight]); place(p + ".ln2.b", [o.LayerNorm2.bias])
+                ffn(p, c.v_intermediate, c.v_output, ".vfi", ".vfo", ".vln")
+                ffn(p, c.t_intermediate, c.t_output, ".tfi", ".tfo", ".tln")
+        self.marks["vlf"] = _round_up(self.off, 64)
+        place("vlf.v.w", [model.vlfusion.fc_v.weight]); place("vlf.v.b", [model.vlfusion.fc_v.bias])
+        place("vlf.l.w", [model.vlfusion.fc_l.weight]); place("vlf.l.b", [model.vlfusion.fc_l.bias])
+        self.marks["dec"] = _round_up(self.off, 64)
+        if self.dec_emb is not self.enc_emb:
+            emb("demb", self.dec_emb)
+        layers = gen.bert.encoder.layer
+        Hd, L = dec_cfg.hidden_size, len(layers)
+        kvw, kvb = [], []
+        for lay in layers:
+            cs = lay.crossattention.self
+            kvw += [cs.key.weight, cs.value.weight]
+            kvb += [cs.key.bias, cs.value.bias]
+        place("dec.ckv.w", kvw, shape=(2 * L * Hd, Hd))
+        place("dec.ckv.b", kvb, shape=(2 * L * Hd,))
+        for i, lay in enumerate(layers):
+            p = "d%d" % i
+            self.marks[("d", i)] = _round_up(self.off, 64)
+            s = lay.attention.self
+            qkv(p, ".qkv", s.query, s.key, s.value, Hd, Hd)
+            attn_out_ffn(p, lay, Hd, dec_cfg.intermediate_size)
+            c = lay.crossattention
+            place(p + ".cq.w", [c.self.query.weight]); place(p + ".cq.b", [c.self.query.bias])
+            place(p + ".co.w", [c.output.dense.weight]); place(p + ".co.b", [c.output.dense.bias])
+            place(p + ".ln2.w", [c.output.LayerNorm.weight]); place(p + ".ln2.b", [c.output.LayerNorm.bias])
+            ffn(p, lay.intermediate, lay.output, ".fi", ".fo", ".ln3")
+        self.marks["lm"] = _round_up(self.off, 64)
+        if id(lm_w) in self.placed:
+            wname = "emb.word" if lm_w is self.enc_emb.word_embeddings.weight else "demb.word"
+            self.slots["lm.w"] = self.slots[wname]
+        else:
+            place("lm.w", [lm_w], shape=(self.Vp, lm_w.shape[1]), pad_rows_to=self.Vp)
+        place("lm.b", [gen.lm_head.bias], shape=(self.Vp,), pad_rows_to=self.Vp)
+        self.n_live = _round_up(self.off, 64)
+        self.live = [p for p, _ in self.items]
+        live_ids = set(id(p) for p in self.live)
+        self.dead = [p for p in model.parameters() if id(p) not in live_ids]
+        self.precision = precision
+        self.P = self.G = self.S = self.D = None
+
+    # -- materialise on the device the parameters currently live on ------------------------------------
+    def materialize(self, device):
+        P = torch.zeros(self.n_live, dtype=torch.float32, device=device)
+        for p, off in self.items:
+            P[off:off + p.numel()].copy_(p.data.reshape(-1))
+        nd = sum(p.numel() for p in self.dead)
+        D = torch.empty(max(nd, 1), dtype=torch.float32, device=device)
+        o = 0
+        for p in self.dead:
+            D[o:o + p.numel()].copy_(p.data.reshape(-1))
+            p.data = D[o:o + p.numel()].view(p.shape)
+            o += p.numel()
+        for p, off in self.items:
+            p.data = P[off:off + p.numel()].view(p.shape)
+        self.P, self.D = P, D
+        self.G = torch.zeros(self.n_live, dtype=torch.float32, device=device)
+        self.S = torch.empty(self.n_live, dtype=torch.bfloat16, device=device) if self.precision == "bf16" else None
+        self.grad_views = [self.G[off:off + p.numel()].view(p.shape) for p, off in self.items]
+        self.ptrs = [(p, P[off:off + p.numel()].data_ptr()) for p, off in self.items]
+        self.shadow_version = None
+        self.device = device
+
+    def is_materialized(self):
+        if self.P is None:
+            return False
+        for p, ptr in self.ptrs:
+            if p.data_ptr() != ptr:
+                return False
+        return True
+
+    def version(self):
+        return sum(p._version for p in self.live)
+
+    def refresh_shadow(self, force=False):
+        if self.S is None:
+            return
+        v = self.version()
+        if force or v != self.shadow_version:
+            ops.cast(self.P, self.S)
+            self.shadow_version = v
+
+    def view(self, buf, name):
+        off, shape = self.slots[name]
+        n = 1
+        for s in shape:
+            n *= s
+        return buf[off:off + n].view(shape)
+
+
+class Engine(object):
+    def __init__(self, model):
+        self.model = model
+        self.enc_cfg, self.dec_cfg = model.encoder.config, model.decoder.config
+        prec = model.params.get("amd_precision", "bf16")
+        if prec not in ("bf16", "fp32"):
+            raise GstvdError("params['amd_precision'] must be 'bf16' or 'fp32'")
+        self.precision = prec
+        self.adt = torch.bfloat16 if prec == "bf16" else torch.float32
+        self.flat = None
+        self.arena = None
+        self.rng = None
+        self.anchor = None
+        self.grad_hook = None          # callable(offset): every gradient at flat offset >= `offset` is final
+        self.tape, self.rec = [], False
+        self.accumulate, self.written = False, set()
+        self.stats = {}
+        self._validate = True
+
+    # ------------------------------------------------------------------------------------------ setup
+    def prepare(self, device):
+        """(Re)build the flat storage if the module tree / device changed (e.g. after `.to(device)` or the
+        embedding aliasing of train_gen.py:293) and make sure the bf16 shadow weights are current."""
+        if device.type != "cuda":
+            raise GstvdError("gst_visdial_amd runs on MI355X only; tensors are on %s (no CPU path)" % device)
+        gen = self.model.decoder.decoder
+        topo = (id(gen.bert.embeddings), id(self.model.encoder.bert_pretrained.bert.embeddings), id(gen.lm_head.decoder.weight))
+        if self.flat is None or self.flat.topo != topo:
+            self.flat = FlatParams(self.model, self.precision)
+            self.flat.topo = topo
+        if not self.flat.is_materialized() or self.flat.device != device:
+            self.flat.materialize(device)
+            self._bind_views()
+        if self.arena is None or self.arena.device != device:
+            self.arena = Arena(device)
+            self.rng = ops.Rng(device, seed=int(self.model.params.get("amd_seed", 0)))
+            self.anchor = torch.zeros(1, device=device, requires_grad=True)
+        self.flat.refresh_shadow()
+
+    def _bind_views(self):
+        f = self.flat
+        wbuf = f.S if self.precision == "bf16" else f.P
+        self.W, self.Pv, self.Gv = {}, {}, {}
+        for name in f.slots:
+            self.Pv[name] = f.view(f.P, name)
+            self.Gv[name] = f.view(f.G, name)
+            self.W[name] = f.view(wbuf, name)
+
+    # ------------------------------------------------------------------------------------------ helpers
+    def buf(self, M, N, dtype=None):
+        return self.arena.alloc(M * N, dtype or self.adt).view(M, N)
+
+    def vec(self, n, dtype=torch.float32):
+        return self.arena.alloc(n, dtype)
+
+    def act(self, M, N):
+        return Act(self.buf(M, N), M, N)
+
+    def site(self):
+        self._site += 1
+        return self._site
+
+    def grad_slot(self, name):
+        g = self.Gv[name]
+        off = self.flat.slots[name][0]
+        acc = self.accumulate or (off in self.written)
+        self.written.add(off)
+        return g, acc
+
+    def push(self, fn):
+        if self.rec:
+            self.tape.append(fn)
+
+    def mark(self, key):
+        if self.rec and self.grad_hook is not None:
+            off = self.flat.marks[key]
+            self.tape.append(lambda: self.grad_hook(off))
+
+    # ------------------------------------------------------------------------------------------ ops
+    def lin(self, x, w, b, N, K, gelu=False, need_dx=True):
+        y = self.act(x.M, N)
+        if gelu:
+            u = self.buf(x.M, N)
+            ops.gemm(x.t, self.W[w], y.t, x.M, N, K, bias=self.Pv[b], aux=u, epi=EPI_GELU)
+            y.gelu_aux = u
+        else:
+            ops.gemm(x.t, self.W[w], y.t, x.M, N, K, bias=self.Pv[b])
+        self.push(lambda: self._lin_bwd(x, y, w, b, N, K, need_dx))
+        return y
+
+    def _lin_bwd(self, x, y, w, b, N, K, need_dx):
+        dy, M = y.g, x.M      # for a GELU output y.g already holds d(pre-activation): its producer applied gelu'
+        gw, acc = self.grad_slot(w)
+        ops.gemm(dy, x.t, gw, N, K, M, a_km=True, b_km=True, addend=gw if acc else None)
+        if not y.bias_done:
+            gb, accb = self.grad_slot(b)
+            scratch = self.vec(((M + 63) // 64) * N)
+            ops.colsum(dy, M, N, gb, scratch, accb)
+        if need_dx:
+            add = x.g
+            if x.g is None:
+                x.g = self.buf(M, K)
+            ops.gemm(dy, self.W[w], x.g, M, K, N, b_km=True, addend=add, aux=x.gelu_aux,
+                     epi=EPI_DGELU if x.gelu_aux is not None else 0)
+
+    def ln(self, x, res, g, b, H, p_pre, bias_name, eps=1e-12):
+        M = x.M
+        y = self.act(M, H)
+        kw = dict(mode=LN_RESID, dtype=ops.dt(x.t), M=M, H=H, gamma=self.Pv[g], beta=self.Pv[b],
+                  mean=self.vec(M), rstd=self.vec(M), eps=eps, x=x.t, res=res.t if res is not None else None, y=y.t,
+                  p_pre=p_pre if self.train else 0.0, site_pre=self.site(), rng=self.rng)
+        ops.ln_fwd(**kw)
+        self.push(lambda: self._ln_bwd(kw, x, res, y, g, b, H, bias_name))
+        return y
+
+    def _colsums(self, partial, nblk, H, names):
+        """Reduce LN-backward partials into up to three gradient slots (None = skip)."""
+        outs, accs = [], []
+        for n in names:
+            if n is None:
+                outs.append(None); accs.append(None)
+            else:
+                gv, a = self.grad_slot(n)
+                outs.append(gv); accs.append(a)
+        flags = set(a for a in accs if a is not None)
+        if len(flags) <= 1:
+            ops.colsum_partials(partial, nblk, 3, H, outs[0], outs[1], outs[2], flags.pop() if flags else False)
+        else:
+            for j in range(3):
+                if outs[j] is not None:
+                    o = [None, None, None]
+                    o[j] = outs[j]
+                    ops.colsum_partials(partial, nblk, 3, H, o[0], o[1], o[2], accs[j])
+
+    def _ln_bwd(self, kw, x, res, y, g, b, H, bias_name):
+        M = x.M
+        nblk = ops.ln_bwd_blocks(M)
+        partial = self.arena.alloc(nblk * 3 * H, torch.float32)
+        if res is not None:
+            if res.g is not None:
+                raise GstvdError("internal: residual gradient written twice")
+            res.g = self.buf(M, H)
+        x.g = self.buf(M, H)
+        ops.ln_bwd(kw, y.g, partial, dres=res.g if res is not None else None, dx=x.g)
+        self._colsums(partial, nblk, H, [g, b, bias_name])
+        x.bias_done = bias_name is not None
+
+    def embed(self, prefix, ids, segs, Bn, T, cfg):
+        M, H = Bn * T, cfg.hidden_size
+        y = self.act(M, H)
+        kw = dict(mode=LN_EMBED, dtype=ops.dt(y.t), M=M, H=H, gamma=self.Pv[prefix + ".ln.w"], beta=self.Pv[prefix + ".ln.b"],
+                  mean=self.vec(M), rstd=self.vec(M), eps=1e-12, y=y.t, ids=ids, segs=segs, T=T,
+                  type_vocab=cfg.type_vocab_size, word=self.Pv[prefix + ".word"], pos=self.Pv[prefix + ".pos"],
+                  tt=self.Pv[prefix + ".tt"], tt_ext=self.Pv[prefix + ".tte"],
+                  p_post=cfg.hidden_dropout_prob if self.train else 0.0, site_post=self.site(), rng=self.rng)
+        ops.ln_fwd(**kw)
+        self.push(lambda: self._embed_bwd(kw, prefix, y, M, H))
+        return y
+
+    def _embed_bwd(self, kw, prefix, y, M, H):
+        tabs = []
+        for n in (".word", ".pos", ".tt", ".tte"):
+            gv, acc = self.grad_slot(prefix + n)
+            if not acc:
+                gv.zero_()
+            tabs.append(gv)
+        nblk = ops.ln_bwd_blocks(M)
+        partial = self.arena.alloc(nblk * 3 * H, torch.float32)
+        ops.ln_bwd(kw, y.g, partial, dword=tabs[0], dpos=tabs[1], dtt=tabs[2], dtt_ext=tabs[3])
+        self._colsums(partial, nblk, H, [prefix + ".ln.w", prefix + ".ln.b", None])
+
+    def img_embed(self, x, loc, cfg):
+        M, H = x.M, cfg.v_hidden_size
+        y = self.act(M, H)
+        kw = dict(mode=LN_IMAGE, dtype=ops.dt(x.t), M=M, H=H, gamma=self.Pv["vemb.ln.w"], beta=self.Pv["vemb.ln.b"],
+                  mean=self.vec(M), rstd=self.vec(M), eps=1e-12, x=x.t, y=y.t, loc=loc, w_loc=self.Pv["vemb.loc.w"],
+                  b_loc=self.Pv["vemb.loc.b"], p_post=cfg.hidden_dropout_prob if self.train else 0.0,
+                  site_post=self.site(), rng=self.rng)
+        ops.ln_fwd(**kw)
+        self.push(lambda: self._img_embed_bwd(kw, x, y, loc, M, H))
+        return y
+
+    def _img_embed_bwd(self, kw, x, y, loc, M, H):
+        nblk = ops.ln_bwd_blocks(M)
+        partial = self.arena.alloc(nblk * 3 * H, torch.float32)
+        x.g = self.buf(M, H)
+        ops.ln_bwd(kw, y.g, partial, dres=x.g)
+        self._colsums(partial, nblk, H, ["vemb.ln.w", "vemb.ln.b", "vemb.loc.b"])
+        self._colsums(partial, nblk, H, [None, None, "vemb.img.b"])
+        x.bias_done = True
+        gw, acc = self.grad_slot("vemb.loc.w")
+        ops.locgrad(x.g, loc, M, H, gw, acc)
+
+    def attn(self, q, k, v, Bn, nh, Lq, Lk, d, key_mask, causal, neg, p):
+        (qa, qc), (ka, kc), (va, vc) = q, k, v
+        Hh = nh * d
+        o = self.act(Bn * Lq, Hh)
+        lse = self.vec(Bn * nh * Lq)
+        a = ops.attn_desc(qa.t[:, qc:qc + Hh], ka.t[:, kc:kc + Hh], va.t[:, vc:vc + Hh], o.t, lse, key_mask, Bn, nh, Lq, Lk, d,
+                          causal=causal, mask_neg=neg, drop_p=p if self.train else 0.0, site=self.site(), rng=self.rng)
+        ops.attn_fwd(a)
+        self.push(lambda: self._attn_bwd(a, q, k, v, o, Bn, nh, Lq, Hh))
+        return o
+
+    def _attn_bwd(self, a, q, k, v, o, Bn, nh, Lq, Hh):
+        gs = []
+        for (act, c) in (q, k, v):
+            if act.g is None:
+                act.g = self.buf(act.M, act.N)
+            gs.append(act.g[:, c:c + Hh])
+        delta = self.vec(Bn * nh * Lq)
+        ops.attn_bwd(a, o.g, gs[0], gs[1], gs[2], delta)
+
+    # ------------------------------------------------------------------------------------------ blocks
+    def self_block(self, p, x, Bn, L, H, nh, key_mask, pa, ph, causal=False):
+        """QKV -> attention -> output dense -> dropout -> LN(+x)   (vilbert_dialog.py:380-431)"""
+        qkv = self.lin(x, p + ".qkv.w", p + ".qkv.b", 3 * H, H)
+        ctx = self.attn((qkv, 0), (qkv, H), (qkv, 2 * H), Bn, nh, L, L, H // nh, key_mask, causal, -10000.0, pa)
+        ao = self.lin(ctx, p + ".ao.w", p + ".ao.b", H, H)
+        return self.ln(ao, x, p + ".ln1.w", p + ".ln1.b", H, ph, p + ".ao.b")
+
+    def ffn_block(self, p, x, H, inter, ph, ti=".fi", to=".fo", tl=".ln2"):
+        """dense+GELU -> dense -> dropout -> LN(+x)   (vilbert_dialog.py:445-462)"""
+        a = self.lin(x, p + ti + ".w", p + ti + ".b", inter, H, gelu=True)
+        fo = self.lin(a, p + to + ".w", p + to + ".b", H, inter)
+        return self.ln(fo, x, p + tl + ".w", p + tl + ".b", H, ph, p + to + ".b")
+
+    def conn_layer(self, p, xv, xt, Bn, R, T, I):
+        """BertConnectionLayer (vilbert_dialog.py:646-773): stream 1 = vision, 2 = text; ctx1 (text queries over
+        vision keys) feeds the text branch, ctx2 the vision branch."""
+        c = self.enc_cfg
+        H, Hv, Hb, nh = c.hidden_size, c.v_hidden_size, c.bi_hidden_size, c.bi_num_attention_heads
+        d = Hb // nh
+        qkv1 = self.lin(xv, p + ".qkv1.w", p + ".qkv1.b", 3 * Hb, Hv)
+        qkv2 = self.lin(xt, p + ".qkv2.w", p + ".qkv2.b", 3 * Hb, H)
+        ctx1 = self.attn((qkv2, 0), (qkv1, Hb), (qkv1, 2 * Hb), Bn, nh, T, R, d, I["vmask"], False, -10000.0,
+                         c.v_attention_probs_dropout_prob)
+        ctx2 = self.attn((qkv1, 0), (qkv2, Hb), (qkv2, 2 * Hb), Bn, nh, R, T, d, I["tmask"], False, -10000.0,
+                         c.attention_probs_dropout_prob)
+        hv = self.lin(ctx2, p + ".d1.w", p + ".d1.b", Hv, Hb)
+        ht = self.lin(ctx1, p + ".d2.w", p + ".d2.b", H, Hb)
+        av = self.ln(hv, xv, p + ".ln1.w", p + ".ln1.b", Hv, c.v_hidden_dropout_prob, p + ".d1.b")
+        at = self.ln(ht, xt, p + ".ln2.w", p + ".ln2.b", H, c.hidden_dropout_prob, p + ".d2.b")
+        ov = self.ffn_block(p, av, Hv, c.v_intermediate_size, c.v_hidden_dropout_prob, ".vfi", ".vfo", ".vln")
+        ot = self.ffn_block(p, at, H, c.intermediate_size, c.hidden_dropout_prob, ".tfi", ".tfo", ".tln")
+        return ov, ot
+
+    def encoder(self, I):
+        """BertModel.forward for enc_dec (vilbert_dialog.py:1325-1407); poolers / cls heads are dead and skipped."""
+        c = self.enc_cfg
+        Bn, T, R = I["B"], I["T"], I["R"]
+        xt = self.embed("emb", I["ids"], I["segs"], Bn, T, c)
+        f = Act(I["feats"], Bn * R, c.v_feature_size)
+        g0 = self.lin(f, "vemb.img.w", "vemb.img.b", c.v_hidden_size, c.v_feature_size, need_dx=I["feats_grad"])
+        xv = self.img_embed(g0, I["loc"], c)
+        I["feats_act"] = f
+        for kind, i in encoder_schedule(c):
+            self.mark((kind, i))
+            if kind == "t":
+                p = "t%d" % i
+                x1 = self.self_block(p, xt, Bn, T, c.hidden_size, c.num_attention_heads, I["tmask"],
+                                     c.attention_probs_dropout_prob, c.hidden_dropout_prob)
+                xt = self.ffn_block(p, x1, c.hidden_size, c.intermediate_size, c.hidden_dropout_prob)
+            elif kind == "v":
+                p = "v%d" % i
+                x1 = self.self_block(p, xv, Bn, R, c.v_hidden_size, c.v_num_attention_heads, I["vmask"],
+                                     c.v_attention_probs_dropout_prob, c.v_hidden_dropout_prob)
+                xv = self.ffn_block(p, x1, c.v_hidden_size, c.v_intermediate_size, c.v_hidden_dropout_prob)
+            else:
+                xv, xt = self.conn_layer("c%d" % i, xv, xt, Bn, R, T, I)
+        return xt, xv
+
+    def fusion(self, xt, xv, I):
+        """VLFusion (visual_dialog_model.py:131-135): cat(fc_v(h_v), fc_l(h_t)) along the sequence, dropout 0.1."""
+        c = self.enc_cfg
+        Bn, T, R = I["B"], I["T"], I["R"]
+        S, H, Hv = R + T, c.hidden_size, c.v_hidden_size
+        self.mark("vlf")
+        enc = self.act(Bn * S, H)
+        p = 0.1 if self.train else 0.0
+        sv, st = self.site(), self.site()
+        e3 = enc.t.view(Bn, S, H)
+        ops.gemm(xv.t, self.W["vlf.v.w"], e3[:, :R], R, H, Hv, bias=self.Pv["vlf.v.b"], batch=Bn, sA=R * Hv, sC=S * H,
+                 lda=Hv, ldc=H, drop_p=p, site=sv, rng=self.rng)
+        ops.gemm(xt.t, self.W["vlf.l.w"], e3[:, R:], T, H, H, bias=self.Pv["vlf.l.b"], batch=Bn, sA=T * H, sC=S * H,
+                 lda=H, ldc=H, drop_p=p, site=st, rng=self.rng)
+        self.push(lambda: self._fusion_bwd(enc, xt, xv, Bn, R, T, H, Hv, p, sv, st))
+        return enc
+
+    def _fusion_bwd(self, enc, xt, xv, Bn, R, T, H, Hv, p, sv, st):
+        yv, yt = self.act(Bn * R, H), self.act(Bn * T, H)
+        yv.g, yt.g = yv.t, yt.t
+        ops.vl_split(enc.g, Bn, R, T, H, yv.g, yt.g, p, sv, st, self.rng)
+        self._lin_bwd(xv, yv, "vlf.v.w", "vlf.v.b", H, Hv, True)
+        self._lin_bwd(xt, yt, "vlf.l.w", "vlf.l.b", H, H, True)
+
+    def decoder(self, enc, I, kv=None):
+        """BertGenerationEncoder + HF BertEncoder (self-attn -> cross-attn -> FFN, post-LN) + LM head."""
+        c = self.dec_cfg
+        Bn, U, S = I["B"], I["U"], I["R"] + I["T"]
+        H, nh, L = c.hidden_size, c.num_attention_heads, c.num_hidden_layers
+        d = H // nh
+        eps = c.layer_norm_eps
+        self.mark("dec")
+        if kv is None:
+            kv = self.lin(enc, "dec.ckv.w", "dec.ckv.b", 2 * L * H, H)
+        y = self.embed("emb" if self.flat.dec_emb is self.flat.enc_emb else "demb", I["dec_ids"], None, Bn, U, c)
+        for i in range(L):
+            p = "d%d" % i
+            self.mark(("d", i))
+            qkv = self.lin(y, p + ".qkv.w", p + ".qkv.b", 3 * H, H)
+            ctx = self.attn((qkv, 0), (qkv, H), (qkv, 2 * H), Bn, nh, U, U, d, I["dmask"], True, -10000.0,
+                            c.attention_probs_dropout_prob)
+            ao = self.lin(ctx, p + ".ao.w", p + ".ao.b", H, H)
+            y1 = self.ln(ao, y, p + ".ln1.w", p + ".ln1.b", H, c.hidden_dropout_prob, p + ".ao.b", eps)
+            q = self.lin(y1, p + ".cq.w", p + ".cq.b", H, H)
+            ctx = self.attn((q, 0), (kv, 2 * i * H), (kv, (2 * i + 1) * H), Bn, nh, U, S, d, I["emask"], False, -1e9,
+                            c.attention_probs_dropout_prob)
+            co = self.lin(ctx, p + ".co.w", p + ".co.b", H, H)
+            y2 = self.ln(co, y1, p + ".ln2.w", p + ".ln2.b", H, c.hidden_dropout_prob, p + ".co.b", eps)
+            a = self.lin(y2, p + ".fi.w", p + ".fi.b", c.intermediate_size, H, gelu=True)
+            fo = self.lin(a, p + ".fo.w", p + ".fo.b", H, c.intermediate_size)
+            y = self.ln(fo, y2, p + ".ln3.w", p + ".ln3.b", H, c.hidden_dropout_prob, p + ".fo.b", eps)
+        self.mark("lm")
+        logits = self.lin(y, "lm.w", "lm.b", self.flat.Vp, H)
+        return y, logits
+
+    # ------------------------------------------------------------------------------------------ step
+    def _inputs(self, feats, loc, img_mask, ids, segs, att_mask, dec_ids, dec_mask):
+        dev = ids.device
+        Bn, T = ids.shape
+        R = feats.shape[1]
+        c = self.enc_cfg
+        if T > c.max_position_embeddings:
+            raise GstvdError("sequence length %d exceeds max_position_embeddings" % T)
+        if segs is None:
+            segs = torch.zeros_like(ids)
+        if self._validate:   # the reference asserts on device every call (vilbert_dialog.py:339); here: first call / on request
+            if int(segs.max()) >= c.type_vocab_size + 10 or int(segs.min()) < 0:
+                raise GstvdError("segment id out of range")
+            if int(ids.max()) >= c.vocab_size or int(ids.min()) < 0 or int(dec_ids.max()) >= c.vocab_size or int(dec_ids.min()) < 0:
+                raise GstvdError("token id out of range")
+            self._validate = bool(self.model.params.get("amd_validate_inputs", False))
+        I = dict(B=Bn, T=T, R=R, U=dec_ids.shape[1])
+        I["ids"], I["segs"] = ids.contiguous().view(-1), segs.contiguous().view(-1)
+        tm = att_mask if att_mask is not None else torch.ones(Bn, T, device=dev)
+        vm = img_mask if img_mask is not None else torch.ones(Bn, R, device=dev)
+        I["tmask"], I["vmask"] = tm.float().contiguous(), vm.float().contiguous()
+        em = self.arena.alloc(Bn * (R + T), torch.float32).view(Bn, R + T)
+        em[:, :R].copy_(I["vmask"])
+        em[:, R:].copy_(I["tmask"])
+        I["emask"] = em
+        I["dmask"] = dec_mask.float().contiguous() if dec_mask is not None else None
+        I["dec_ids"] = dec_ids.contiguous().view(-1)
+        f2 = feats.reshape(Bn * R, feats.shape[-1])
+        if self.adt == torch.float32:
+            I["feats"] = f2.float().contiguous()
+        else:
+            fb = self.buf(Bn * R, f2.shape[1])
+            ops.cast(f2.float().contiguous(), fb)
+            I["feats"] = fb
+        I["loc"] = loc.reshape(Bn * R, 5).float().contiguous()
+        I["feats_grad"] = bool(feats.requires_grad and torch.is_grad_enabled())
+        return I
+
+    def _begin(self, device, record):
+        self.prepare(device)
+        self.arena.reset()
+        self.tape, self.rec = [], record
+        self._site = 0
+        self.train = bool(self.model.training)
+        if self.train:
+            self.rng.advance()
+
+    def step(self, feats, loc, img_mask, ids, segs, att_mask, dec_ids, dec_mask, labels, loss_reduction=True):
+        """EncoderDecoderModel.forward, train/eval branch -> (loss, logits)."""
+        record = torch.is_grad_enabled()
+        self._begin(ids.device, record)
+        dc = self.dec_cfg
+        if labels is None:    # visual_dialog_decoder.py:53-57: shift left, then mutate the caller's ids in place
+            labels = dec_ids.new_zeros(dec_ids.shape)
+            labels[:, :-1] = dec_ids[:, 1:].clone()
+            dec_ids.masked_fill_(dec_ids == dc.eos_token_id, dc.pad_token_id)
+        I = self._inputs(feats, loc, img_mask, ids, segs, att_mask, dec_ids, dec_mask)
+        Bn, U, V = I["B"], I["U"], dc.vocab_size
+        xt, xv = self.encoder(I)
+        enc = self.fusion(xt, xv, I)
+        y, logits = self.decoder(enc, I)
+        Md = Bn * U
+        lab = labels.contiguous().view(-1)
+        row_loss, lse, stats = self.vec(Md), self.vec(Md), self.vec(4)
+        ops.ce_fwd(logits.t, lab, Md, V, row_loss, lse, stats, ignore_index=dc.pad_token_id)
+        st = dict(I=I, logits=logits, lab=lab, lse=lse, stats=stats, Md=Md, V=V, mean=bool(loss_reduction), tape=self.tape,
+                  pad=dc.pad_token_id)
+        self.last = dict(enc_t=xt, enc_v=xv, enc=enc, dec_hidden=y, logits=logits, lse=lse, row_loss=row_loss)
+        lv = logits.t.view(Bn, U, self.flat.Vp)[:, :, :V]
+        if record:
+            loss_raw = stats[2] if loss_reduction else row_loss
+            loss = _StepFn.apply(self.anchor, feats if I["feats_grad"] else None, self, st, loss_raw)
+            return loss, lv
+        loss = stats[2].clone() if loss_reduction else row_loss.clone()
+        return loss, lv.float()
+
+    def backward(self, st, gloss):
+        """Replay the tape: fills the flat gradient buffer, assigns `.grad` views, returns d loss / d image features."""
+        flat = self.flat
+        if not st["mean"]:
+            raise GstvdError("backward through loss_reduction=False is not supported (the reference never does it)")
+        have = [p.grad is not None for p in flat.live]
+        self.accumulate = any(have)
+        if self.accumulate:
+            for p, gv in zip(flat.live, flat.grad_views):
+                if p.grad is None:
+                    gv.zero_()
+                elif p.grad.data_ptr() != gv.data_ptr():
+                    gv.copy_(p.grad)
+        self.written = set()
+        logits = st["logits"]
+        logits.g = self.buf(st["Md"], flat.Vp)
+        gs = gloss.reshape(1).float().contiguous() if gloss is not None else None
+        ops.ce_bwd(logits.t, st["lab"], st["lse"], st["stats"], gs, True, st["Md"], st["V"], logits.g, ignore_index=st["pad"])
+        for fn in reversed(st["tape"]):
+            fn()
+        if self.grad_hook is not None:
+            self.grad_hook(0)
+        for p, gv in zip(flat.live, flat.grad_views):
+            p.grad = gv
+        fa = st["I"].get("feats_act")
+        if st["I"]["feats_grad"] and fa is not None and fa.g is not None:
+            return fa.g.float()
+        return None
+
+    # ------------------------------------------------------------------------------------------ sampling decode
+    @torch.no_grad()
+    def sample(self, feats, loc, img_mask, ids, segs, att_mask, dec_ids, temperature=1.0, top_k=0, top_p=0.0,
+               ngram_blocking_size=0, max_seq_len=18, **_):
+        """models/visual_dialog_model.py:74-120: 18 steps of full-prefix decoding with temperature, n-gram blocking
+        and top-k/top-p filtering, multinomial draw, [PAD] after the first [SEP].  The encoder and the cross K/V
+        projection run once; token-id work (filters, n-gram ban, EOS fill) is integer-exact host/torch plumbing."""
+        from . import decoding
+        self._begin(ids.device, False)
+        self.train = False
+        dc = self.dec_cfg
+        start_ids = dec_ids
+        I = self._inputs(feats, loc, img_mask, ids, segs, att_mask, start_ids, None)
+        xt, xv = self.encoder(I)
+        enc = self.fusion(xt, xv, I)
+        Bn, V = I["B"], dc.vocab_size
+        hist = ids * (segs == 0).long()
+        cur = start_ids
+        seq = []
+        L, Hd = dc.num_hidden_layers, dc.hidden_size
+        kv = self.lin(enc, "dec.ckv.w", "dec.ckv.b", 2 * L * Hd, Hd)      # cross K/V of all layers, once
+        mark_ci, mark_off = self.arena.ci, self.arena.off
+        for _ in range(max_seq_len):
+            self.arena.ci, self.arena.off = mark_ci, mark_off
+            I["U"], I["dec_ids"], I["dmask"] = cur.shape[1], cur.contiguous().view(-1), None
+            _, logits = self.decoder(enc, I, kv)
+            U = cur.shape[1]
+            last = logits.t.view(Bn, U, self.flat.Vp)[:, -1, :V].float() / temperature
+            last = decoding.batch_ngram_blocking(last, hist, cur, ngram_size=ngram_blocking_size)
+            last = decoding.batch_top_k_top_p_sampling(last, top_k=top_k, top_p=top_p)
+            nxt = torch.multinomial(torch.softmax(last, dim=-1), 1)
+            cur = torch.cat((cur, nxt), dim=-1)
+            seq.append(nxt)
+        return decoding.pad_after_eos(torch.cat(seq, 1), dc.eos_token_id, dc.pad_token_id)
+
+
+class _StepFn(torch.autograd.Function):
+    """Bridges the hand-written backward into torch.autograd so `loss.backward()` (train_gen.py:324) and
+    d loss / d enc_image_features (FGSM in evaluate_gen_attack.py:101-131) keep working."""
+
+    @staticmethod
+    def forward(ctx, anchor, feats, engine, st, loss_raw):
+        ctx.engine, ctx.st = engine, st
+        ctx.has_feats = feats is not None
+        ctx.feats_shape = feats.shape if feats is not None else None
+        return loss_raw.clone()
+
+    @staticmethod
+    def backward(ctx, gloss):
+        dfe = ctx.engine.backward(ctx.st, gloss)
+        if ctx.has_feats and dfe is not None:
+            dfe = dfe.view(ctx.feats_shape)
+        return None, dfe, None, None, None
+
+
+# ---- stand-alone encoder / decoder calls (inference plumbing; no autograd) --------------------------------
+def _owner_engine(module, kind):
+    eng = getattr(module, "_standalone_engine", None)
+    if eng is None:
+        raise GstvdError("%s.forward outside an EncoderDecoderModel is not supported by the MI355X engine; "
+                         "call EncoderDecoderModel(...) (the reference scripts only ever do that)" % kind)
+    return eng
+
+
+def standalone_encoder_forward(module, input_ids, image_feat, image_loc, token_type_ids, attention_mask, image_attention_mask):
+    eng = _owner_engine(module, "VisualDialogEncoder")
+    with torch.no_grad():
+        eng._begin(input_ids.device, False)
+        dummy = input_ids.new_zeros(input_ids.shape[0], 1)
+        I = eng._inputs(image_feat, image_loc, image_attention_mask, input_ids, token_type_ids, attention_mask, dummy, None)
+        xt, xv = eng.encoder(I)
+        Bn = I["B"]
+        return xt.t.view(Bn, I["T"], -1).float(), xv.t.view(Bn, I["R"], -1).float()
+
+
+def standalone_decoder_forward(module, dec_ids, attention_mask, enc_hidden, enc_mask, labels, loss_reduction):
+    raise GstvdError("VisualDialogDecoder.forward outside an EncoderDecoderModel is not supported by the MI355X engine")

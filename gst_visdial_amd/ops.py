@@ -183,6 +183,12 @@ def answer_scores(logits, lse, dec_ids, rows, U, scores):
                                                            dt(logits), _p(scores), _stream()))
 
 
+def vl_split(d_enc, B, R, T, H, d_v, d_t, p, site_v, site_t, rng):
+    lib = L.load()
+    L.check("gstvd_vl_split", lib.gstvd_vl_split(_p(d_enc), B, R, T, H, dt(d_enc), _p(d_v), _p(d_t), p, site_v, site_t,
+                                                 rng.ptr() if (rng is not None and p > 0) else None, _stream()))
+
+
 def cast(src, dst, n=None):
     lib = L.load()
     n = src.numel() if n is None else n

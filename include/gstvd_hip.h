@@ -146,9 +146,9 @@ int gstvd_attn_fwd(const gstvd_attn_t* a, gstvd_stream_t s);
 int gstvd_attn_bwd(const gstvd_attn_t* a, gstvd_stream_t s);  /* dQ (+delta) then dK,dV */
 
 /* ---- LM head loss: CrossEntropyLoss(ignore_index) of visual_dialog_decoder.py:70-77 ----------
- * logits [M, ldl >= V]; row_loss [M] (0 for ignored rows); stats[0] = sum of row losses,
- * stats[1] = number of non-ignored rows (both fp32, zeroed by the call); lse [M] saved.
- * mean loss = stats[0] / stats[1]. */
+ * logits [M, ldl >= V]; row_loss [M] (0 for ignored rows); stats (fp32[3], written by the call):
+ * stats[0] = sum of row losses, stats[1] = number of non-ignored rows, stats[2] = mean loss
+ * (= stats[0] / stats[1], NaN when every row is ignored, like torch); lse [M] saved. */
 int gstvd_ce_fwd(const void* logits, int64_t ldl, const int64_t* labels, int64_t M, int64_t V,
                  int64_t ignore_index, int32_t dtype, float* row_loss, float* lse, float* stats,
                  gstvd_stream_t s);
@@ -160,6 +160,12 @@ int gstvd_ce_bwd(const void* logits, int64_t ldl, const int64_t* labels, const f
 /* evaluate_gen.py:94-106: score[m] = sum_u [tgt != 0] * (logits[m,u,tgt] - lse[m,u]) with tgt = ids shifted left */
 int gstvd_answer_scores(const void* logits, int64_t ldl, const float* lse, const int64_t* dec_ids,
                         int64_t rows, int64_t U, int32_t dtype, float* scores, gstvd_stream_t s);
+
+/* backward of VLFusion's concat + dropout (visual_dialog_model.py:132-133): d_enc [B, R+T, H] ->
+ * d_v [B*R, H] (vision rows first) and d_t [B*T, H], each multiplied by the dropout mask its forward GEMM
+ * epilogue applied (element index (b*R + r)*H + n under site_v, (b*T + t)*H + n under site_t). */
+int gstvd_vl_split(const void* d_enc, int64_t B, int64_t R, int64_t T, int64_t H, int32_t dtype, void* d_v, void* d_t,
+                   float p, uint32_t site_v, uint32_t site_t, const uint64_t* rng, gstvd_stream_t s);
 
 /* ---- element-wise plumbing --------------------------------------------------------------------*/
 int gstvd_cast(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t n, gstvd_stream_t s);
