@@ -93,3 +93,25 @@ def encoder_schedule(cfg):
     order += [("v", i) for i in range(vs, cfg.v_num_hidden_layers)]
     order += [("t", i) for i in range(ts, cfg.num_hidden_layers)]
     return order
+
+
+def bert_base_enc_config():
+    """The values of the reference's config/bert_base_6layer_6conect_enc.json (12 text / 6 vision / 6 connection layers)."""
+    return dict(attention_probs_dropout_prob=0.1, hidden_act="gelu", hidden_dropout_prob=0.3, hidden_size=768,
+                initializer_range=0.02, intermediate_size=3072, max_position_embeddings=512, model_type="bert-generation",
+                num_attention_heads=12, num_hidden_layers=12, type_vocab_size=2, vocab_size=30522, v_feature_size=2048,
+                v_target_size=1601, v_hidden_size=1024, v_num_hidden_layers=6, v_num_attention_heads=8,
+                v_intermediate_size=1024, bi_hidden_size=1024, bi_num_attention_heads=8, bi_intermediate_size=1024,
+                bi_attention_type=1, v_attention_probs_dropout_prob=0.1, v_hidden_act="gelu", v_hidden_dropout_prob=0.3,
+                v_initializer_range=0.02, v_biattention_id=[0, 1, 2, 3, 4, 5], t_biattention_id=[6, 7, 8, 9, 10, 11],
+                pooling_method="mul")
+
+
+def bert_base_dec_config():
+    """The values of the reference's config/bert_base_6layer_6conect_dec.json (12-layer decoder with cross-attention)."""
+    return dict(attention_probs_dropout_prob=0.1, hidden_act="gelu", hidden_dropout_prob=0.3, hidden_size=768,
+                initializer_range=0.02, intermediate_size=3072, max_position_embeddings=512, model_type="bert-generation",
+                num_attention_heads=12, num_hidden_layers=12, type_vocab_size=2, vocab_size=30522, v_feature_size=2048,
+                v_target_size=1601, v_hidden_size=1024, v_num_hidden_layers=6, v_num_attention_heads=8,
+                v_intermediate_size=1024, add_cross_attention=True, is_decoder=True, layer_norm_eps=1e-12, bos_token_id=101,
+                eos_token_id=102, use_cache=False, decoder_start_token_id=101, pad_token_id=0)

@@ -30,6 +30,57 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class Profiler(object):
+    """Optional per-launch timing with HIP events on the launch stream (bench.py's kernel breakdown).
+    Off by default; `with ops.Profiler() as p:` records (tag, flops, bytes, start, end) per wrapped call."""
+    active = None
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        Profiler.active = self
+        return self
+
+    def __exit__(self, *a):
+        Profiler.active = None
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for tag, flops, nbytes, e0, e1 in self.records:
+            a = agg.setdefault(tag, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            a["launches"] += 1
+            a["ms"] += e0.elapsed_time(e1)
+            a["flops"] += flops
+            a["bytes"] += nbytes
+        return agg
+
+
+def _prof_begin():
+    if Profiler.active is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _prof_end(e0, tag, flops=0.0, nbytes=0.0):
+    if e0 is None:
+        return
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record()
+    Profiler.active.records.append((tag, flops, nbytes, e0, e1))
+
+
+def gemm_tag(dtype_in, a_km, b_km, M, N, batch):
+    """Name of the kernel instantiation gstvd_gemm dispatches to (same rule as launch_layout in csrc/gemm.hip)."""
+    big = ((M + 127) // 128) * ((N + 127) // 128) * batch
+    tile = 128 if (M >= 256 and N >= 128 and big >= 96) else 64
+    lay = {(0, 0): "nt", (0, 1): "nn", (1, 1): "tn", (1, 0): "tt"}[(int(a_km), int(b_km))]
+    return "gemm_%s_%s_%d" % ("bf16" if dtype_in == BF16 else "f32", lay, tile)
+
+
 class Rng:
     """Device-resident (seed, offset) pair read by every dropout site; graph-capture safe."""
 
@@ -71,7 +122,10 @@ def gemm(A, B, C_out, M, N, K, *, a_km=False, b_km=False, bias=None, addend=None
     d.epilogue = epi
     d.alpha, d.dropout_p, d.site = alpha, drop_p, site
     d.rng = rng.ptr() if (rng is not None and drop_p > 0) else None
+    e0 = _prof_begin()
     L.check("gstvd_gemm", lib.gstvd_gemm(C.byref(d), _stream()))
+    _prof_end(e0, gemm_tag(d.dtype_in, a_km, b_km, M, N, batch), 2.0 * M * N * K * batch,
+              float(batch) * ((M * K + N * K) * A.element_size() + M * N * C_out.element_size()))
     return C_out
 
 
@@ -96,7 +150,9 @@ def _ln_desc(mode, dtype, M, H, gamma, beta, mean, rstd, eps, x=None, res=None, 
 def ln_fwd(**kw):
     lib = L.load()
     d = _ln_desc(**kw)
+    e0 = _prof_begin()
     L.check("gstvd_ln_fwd", lib.gstvd_ln_fwd(C.byref(d), _stream()))
+    _prof_end(e0, "ln_fwd", 0.0, 3.0 * d.M * d.H * (2 if d.dtype == BF16 else 4))
 
 
 def ln_bwd_blocks(M):
@@ -112,19 +168,25 @@ def ln_bwd(fwd_kw, dy, partial, dres=None, dx=None, dword=None, dpos=None, dtt=N
     b.dx, b.lddx = _p(dx), (dx.stride(-2) if dx is not None else 0)
     b.partial = _p(partial)
     b.dword, b.dpos, b.dtt, b.dtt_ext = _p(dword), _p(dpos), _p(dtt), _p(dtt_ext)
+    e0 = _prof_begin()
     L.check("gstvd_ln_bwd", lib.gstvd_ln_bwd(C.byref(b), _stream()))
+    _prof_end(e0, "ln_bwd", 0.0, 5.0 * b.f.M * b.f.H * (2 if b.f.dtype == BF16 else 4))
 
 
 def colsum_partials(partial, nblk, nvec, H, out0, out1, out2, accumulate):
     lib = L.load()
+    e0 = _prof_begin()
     L.check("gstvd_colsum_partials", lib.gstvd_colsum_partials(_p(partial), nblk, nvec, H, _p(out0), _p(out1), _p(out2),
                                                                int(accumulate), _stream()))
+    _prof_end(e0, "colsum_partials", 0.0, 4.0 * nblk * nvec * H)
 
 
 def colsum(x, M, N, out, scratch, accumulate):
     lib = L.load()
+    e0 = _prof_begin()
     L.check("gstvd_colsum", lib.gstvd_colsum(_p(x), x.stride(-2), M, N, dt(x), _p(out), _p(scratch), scratch.numel(),
                                              int(accumulate), _stream()))
+    _prof_end(e0, "colsum", 0.0, float(M) * N * x.element_size())
 
 
 def locgrad(dh, loc, M, H, dw_loc, accumulate):
@@ -151,7 +213,9 @@ def attn_desc(Q, K, V, O, LSE, key_mask, B, nh, Lq, Lk, d, *, causal=False, mask
 
 def attn_fwd(a):
     lib = L.load()
+    e0 = _prof_begin()
     L.check("gstvd_attn_fwd", lib.gstvd_attn_fwd(C.byref(a), _stream()))
+    _prof_end(e0, "attn_fwd_d%d" % a.d, 4.0 * a.B * a.nh * a.Lq * a.Lk * a.d)
 
 
 def attn_bwd(a, dO, dQ, dK, dV, delta, lddo=None, lddq=None, lddk=None, lddv=None):
@@ -161,7 +225,9 @@ def attn_bwd(a, dO, dQ, dK, dV, delta, lddo=None, lddq=None, lddk=None, lddv=Non
     a.lddq = dQ.stride(-2) if lddq is None else lddq
     a.lddk = dK.stride(-2) if lddk is None else lddk
     a.lddv = dV.stride(-2) if lddv is None else lddv
+    e0 = _prof_begin()
     L.check("gstvd_attn_bwd", lib.gstvd_attn_bwd(C.byref(a), _stream()))
+    _prof_end(e0, "attn_bwd_d%d" % a.d, 14.0 * a.B * a.nh * a.Lq * a.Lk * a.d)
 
 
 def ce_fwd(logits, labels, M, V, row_loss, lse, stats, ignore_index=0):
@@ -210,5 +276,7 @@ def dropout_mask(n, p, site, rng, device):
 
 def adamw(param, grad, m, v, shadow, seg_end, hp, step, beta1=0.9, beta2=0.999, eps=1e-6, grad_scale=1.0):
     lib = L.load()
+    e0 = _prof_begin()
     L.check("gstvd_adamw", lib.gstvd_adamw(_p(param), _p(grad), _p(m), _p(v), _p(shadow), param.numel(), _p(seg_end), _p(hp),
                                            seg_end.numel(), beta1, beta2, eps, _p(step), grad_scale, _stream()))
+    _prof_end(e0, "adamw", 0.0, param.numel() * (30.0 if shadow is not None else 28.0))
