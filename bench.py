@@ -212,8 +212,12 @@ def main():
                              gbps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None)
                      for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
         if args.breakdown_json:
+            shapes = prof.summary(by_shape=True)
+            shp = {k: dict(launches=v["launches"], ms=round(v["ms"], 3), us_per_launch=round(1e3 * v["ms"] / v["launches"], 1),
+                           tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None)
+                   for k, v in sorted(shapes.items(), key=lambda kv: -kv[1]["ms"])}
             with open(args.breakdown_json, "w") as f:
-                json.dump({"ms_per_step": ms_step, "kernels": breakdown}, f, indent=1)
+                json.dump({"ms_per_step": ms_step, "kernels": breakdown, "shapes": shp}, f, indent=1)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

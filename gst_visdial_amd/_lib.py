@@ -53,6 +53,11 @@ class AttnDesc(C.Structure):
                 ("lddq", _i64), ("lddk", _i64), ("lddv", _i64), ("delta", _vp)]
 
 
+class ColsumEntry(C.Structure):
+    _fields_ = [("partial", _vp), ("out", _vp * 3), ("nblk", _i64), ("stride", _i64), ("H", _i64),
+                ("nvec", _i32), ("accumulate", _i32 * 3), ("blk0", _i32)]
+
+
 # name -> (restype, argtypes); every symbol include/gstvd_hip.h declares
 SIGNATURES = {
     "gstvd_abi_version": (_i32, []),
@@ -62,6 +67,8 @@ SIGNATURES = {
     "gstvd_ln_bwd_blocks": (_i64, [_i64]),
     "gstvd_ln_bwd": (_i32, [C.POINTER(LnBwdDesc), _vp]),
     "gstvd_colsum_partials": (_i32, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _i32, _vp]),
+    "gstvd_colsum_batched": (_i32, [_vp, _i64, _i64, _vp]),
+    "gstvd_colsum_slabs": (_i32, [_vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp]),
     "gstvd_colsum": (_i32, [_vp, _i64, _i64, _i64, _i32, _vp, _vp, _i64, _i32, _vp]),
     "gstvd_locgrad": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _vp, _i32, _vp]),
     "gstvd_attn_fwd": (_i32, [C.POINTER(AttnDesc), _vp]),

@@ -11,94 +11,7 @@
 //    blocks) -- no transposing pass anywhere;
 //  * the MFMA is issued "swapped" (n on the accumulator rows) so each lane owns 4 consecutive n of one
 //    output row and the epilogue stores 8/16 bytes per lane.
-#include "common.h"
-
-struct GemmP {
-  const char* A; const char* B; char* C;
-  const float* bias; const char* addend; char* aux;
-  int64_t M, N, K, lda, ldb, ldc, ldadd, ldaux, sA, sB, sC, sAdd, sAux;
-  int epi; float alpha, p; uint32_t site; const uint64_t* rng;
-};
-
-template <typename T> struct TileCfg;
-template <> struct TileCfg<bf16> { static constexpr int VE = 8, BK = 64; };
-template <> struct TileCfg<float> { static constexpr int VE = 4, BK = 32; };
-
-// ---- LDS images -------------------------------------------------------------------------------
-// row-major image: BX rows of 128 bytes (BK elements); 16-byte slot s of row r lives at slot s ^ (r & 7)
-DEVFN int rm_off(int row, int slot) { return row * 128 + (((slot ^ row) & 7) << 4); }
-// k-major bf16 image: BK rows of BX*2 bytes; 32-byte block b of k-row r lives at block b ^ f(r)
-template <int BX> DEVFN int km_off_bf16(int krow, int col) {
-  constexpr int NB = BX / 16;
-  int f = (krow & 3) | (((krow >> 3) & 1) << 2);
-  int blk = ((col >> 4) ^ f) & (NB - 1);
-  return krow * (BX * 2) + (blk << 5) + ((col & 15) << 1);
-}
-template <int BX> constexpr int km_row_bytes_f32() { return (BX + 4) * 4; }
-
-template <typename T, int BX, bool KM> constexpr int image_bytes() {
-  return KM ? (sizeof(T) == 2 ? TileCfg<T>::BK * BX * 2 : TileCfg<T>::BK * km_row_bytes_f32<BX>()) : BX * 128;
-}
-
-// ---- global -> registers ----------------------------------------------------------------------
-template <typename T, int BX, bool KM, int NT, int NV>
-DEVFN void load_tile(u32x4 (&reg)[NV], const char* g, int64_t ld, int64_t x0, int64_t X, int64_t k0, int64_t K, int tid) {
-  constexpr int VE = TileCfg<T>::VE, BK = TileCfg<T>::BK;
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    int v = tid + i * NT;
-    int64_t x, k;
-    if (KM) { constexpr int VPR = BX / VE; k = k0 + v / VPR; x = x0 + (v % VPR) * VE; }
-    else    { constexpr int VPR = BK / VE; x = x0 + v / VPR; k = k0 + (v % VPR) * VE; }
-    u32x4 z = {0u, 0u, 0u, 0u};
-    if (x < X && k < K) {
-      const char* ptr = g + (KM ? (k * ld + x) : (x * ld + k)) * (int64_t)sizeof(T);
-      z = *(const u32x4*)ptr;
-    }
-    reg[i] = z;
-  }
-}
-// ---- registers -> LDS image ---------------------------------------------------------------------
-template <typename T, int BX, bool KM, int NT, int NV>
-DEVFN void store_tile(const u32x4 (&reg)[NV], char* img, int tid) {
-  constexpr int VE = TileCfg<T>::VE, BK = TileCfg<T>::BK;
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    int v = tid + i * NT;
-    int off;
-    if (KM) {
-      constexpr int VPR = BX / VE;
-      int kr = v / VPR, cv = v % VPR;
-      off = (sizeof(T) == 2) ? km_off_bf16<BX>(kr, cv * VE) : kr * km_row_bytes_f32<BX>() + cv * 16;
-    } else {
-      constexpr int VPR = BK / VE;
-      off = rm_off(v / VPR, v % VPR);
-    }
-    *(u32x4*)(img + off) = reg[i];
-  }
-}
-
-// ---- LDS image -> MFMA fragment ----------------------------------------------------------------
-// bf16: 8 elements k = kk*32 + 8g + j for x = xb + (lane & 15)
-template <int BX, bool KM> DEVFN bf16x8 frag_bf16(const char* img, int xb, int kk, int lane) {
-  int g = lane >> 4, li = lane & 15;
-  if (!KM) {
-    return *(const bf16x8*)(img + rm_off(xb + li, kk * 4 + g));
-  } else {
-    int kr = kk * 32 + 8 * g + (li >> 2), col = xb + 4 * (lane & 3);
-    s16x4 lo = lds_tr16(img + km_off_bf16<BX>(kr, col));
-    s16x4 hi = lds_tr16(img + km_off_bf16<BX>(kr + 4, col));
-    typedef __attribute__((ext_vector_type(8))) short s16x8;
-    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8, v);
-  }
-}
-// f32: one element k = ks*4 + g for x = xb + (lane & 15)
-template <int BX, bool KM> DEVFN float frag_f32(const char* img, int xb, int ks, int lane) {
-  int g = lane >> 4, li = lane & 15;
-  if (!KM) return *(const float*)(img + rm_off(xb + li, ks) + g * 4);
-  return *(const float*)(img + (ks * 4 + g) * km_row_bytes_f32<BX>() + (xb + li) * 4);
-}
+#include "gemm_common.h"
 
 template <typename T, typename OT, int BM, int BN, int WM, int WN, bool AKM, bool BKM>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmP p) {
@@ -177,38 +90,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmP p) {
   // ---- epilogue: lane owns C[m = .. + (lane&15)][n = .. + 4*(lane>>4) + 0..3] ---------------------
   const int g = lane >> 4, li = lane & 15;
   const DropKey dk = make_drop((p.epi & GSTVD_EPI_DROPOUT) ? p.p : 0.f, p.site, p.rng);
-  OT* C = (OT*)p.C + z * p.sC;
-  const OT* ADD = (const OT*)p.addend + z * p.sAdd;
-  T* AUX = (T*)p.aux + z * p.sAux;
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int64_t m = m0 + wm * WTM + i * 16 + li;
-    if (m >= p.M) continue;
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int64_t n = n0 + wn * WTN + j * 16 + 4 * g;
-      if (n >= p.N) continue;
-      f32x4 v = acc[i][j] * p.alpha;
-      if (p.epi & GSTVD_EPI_BIAS) v += *(const f32x4*)(p.bias + n);
-      if (p.epi & GSTVD_EPI_ADD) v += ld4(ADD + m * p.ldadd + n);
-      if (p.epi & GSTVD_EPI_GELU) {
-        st4(AUX + m * p.ldaux + n, v);
-        v = (f32x4){gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])};
-      }
-      if (p.epi & GSTVD_EPI_DGELU) {
-        f32x4 u = ld4(AUX + m * p.ldaux + n);
-        v *= (f32x4){dgelu_f(u[0]), dgelu_f(u[1]), dgelu_f(u[2]), dgelu_f(u[3])};
-      }
-      if (dk.on) v *= drop_factor4(dk, (uint64_t)((z * p.M + m) * p.N + n));
-      st4(C + m * p.ldc + n, v);
-    }
-  }
-}
-
-template <typename K> static int ensure_lds(K kernel, int bytes) {
-  if (bytes <= 48 * 1024) return 0;
-  hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  return e == hipSuccess ? 0 : (int)e;
+    for (int j = 0; j < NI; ++j)
+      gemm_epilogue_tile<T, OT>(p, dk, acc[i][j], z, m0 + wm * WTM + i * 16 + li, n0 + wn * WTN + j * 16 + 4 * g);
 }
 
 template <typename T, typename OT, int BM, int BN, bool AKM, bool BKM>
@@ -262,6 +148,10 @@ extern "C" int gstvd_gemm(const gstvd_gemm_t* g, gstvd_stream_t stream) {
   p.sA = g->sA; p.sB = g->sB; p.sC = g->sC; p.sAdd = g->sAdd; p.sAux = g->sAux;
   p.epi = g->epilogue; p.alpha = g->alpha; p.p = g->dropout_p; p.site = g->site; p.rng = g->rng;
   hipStream_t s = (hipStream_t)stream;
+  if (g->dtype_in == GSTVD_BF16 && (g->dtype_out == GSTVD_BF16 || g->dtype_out == GSTVD_F32)) {
+    int rc = gemm_dma_dispatch(p, g->batch, g->a_kmajor, g->b_kmajor, g->dtype_out == GSTVD_F32, s);
+    if (rc != GSTVD_E_UNSUPPORTED) return rc;
+  }
   if (g->dtype_in == GSTVD_BF16 && g->dtype_out == GSTVD_BF16) return launch_dtype<bf16, bf16>(p, g->batch, g->a_kmajor, g->b_kmajor, s);
   if (g->dtype_in == GSTVD_BF16 && g->dtype_out == GSTVD_F32) return launch_dtype<bf16, float>(p, g->batch, g->a_kmajor, g->b_kmajor, s);
   if (g->dtype_in == GSTVD_F32 && g->dtype_out == GSTVD_F32) return launch_dtype<float, float>(p, g->batch, g->a_kmajor, g->b_kmajor, s);

@@ -1,0 +1,180 @@
+// bf16 MFMA GEMM main loop with direct-to-LDS loads (global_load_lds_dwordx4) and an NS-deep LDS ring.
+//
+// Why: the GEMMs of this path are short-K (768..3072) and often skinny (M = 400/592 rows), so a workgroup
+// spends its life in the load->use latency chain.  Here every thread keeps (NS-1) K-tiles of LDS-DMA in
+// flight, waits with a COUNTED s_waitcnt vmcnt (never 0 inside the loop), and there is one raw s_barrier per
+// K-tile.  No staging registers, no ds_write pass.
+//
+//  * LDS-DMA writes wave-uniform base + lane*16, i.e. the LDS image is lane-linear; the XOR swizzle that
+//    makes ds_read_b128 / ds_read_b64_tr_b16 conflict-free is therefore applied to the per-lane SOURCE
+//    address (and, identically, to the read address) -- cdna guide rule 21;
+//  * tails (M, N, K not tile multiples) never mask lanes: an out-of-range 16-byte unit reads a device-side
+//    zero page instead, so contraction tails are zero filled and the DMA count per stage stays constant;
+//  * blockIdx is remapped so that each XCD (private L2) walks a contiguous range of output tiles.
+#include "gemm_common.h"
+#include <stdlib.h>
+
+__device__ __attribute__((aligned(256))) char g_zero_page[256];
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+DEVFN void glds16(const char* src, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
+// Per-thread description of the 16-byte units this thread feeds into one operand image, fixed over the K loop.
+template <int BX, bool KM, int NP, int NT>
+struct DmaUnits {
+  const char* ptr[NP];   // address of the unit in K-tile 0 (meaningless when !okx)
+  int kofs[NP];          // k index of the unit inside a K-tile
+  bool okx[NP];
+  int64_t kstep;         // byte advance per K-tile
+
+  DEVFN void init(const char* g, int64_t ld, int64_t x0, int64_t X, int tid) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int u = i * NT + tid;
+      int64_t x;
+      if (!KM) {
+        const int r = u >> 3, ls = ((u & 7) ^ r) & 7;
+        x = x0 + r;
+        kofs[i] = ls * 8;
+        ptr[i] = g + (x * ld + ls * 8) * 2;
+      } else {
+        constexpr int VPR = BX / 8, NB = BX / 16;
+        const int kr = u / VPR, cu = u % VPR;
+        const int f = (kr & 3) | (((kr >> 3) & 1) << 2);
+        const int lb = ((cu >> 1) ^ f) & (NB - 1);
+        x = x0 + lb * 16 + (cu & 1) * 8;
+        kofs[i] = kr;
+        ptr[i] = g + ((int64_t)kr * ld + x) * 2;
+      }
+      okx[i] = x < X;
+    }
+    kstep = KM ? 64 * ld * 2 : 128;
+  }
+  DEVFN void issue(int64_t kt, int64_t K, char* img, int wave) const {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const bool ok = okx[i] && (kt * 64 + kofs[i] < K);
+      const char* src = ok ? ptr[i] + kt * kstep : (const char*)g_zero_page;
+      glds16(src, img + (i * NT + wave * 64) * 16);
+    }
+  }
+};
+
+template <typename OT, int BM, int BN, int WM, int WN, bool AKM, bool BKM, int NS>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(GemmP p, int ntn, int nwg) {
+  constexpr int NT = WM * WN * 64, WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int NPA = A_BYTES / (NT * 16), NPB = B_BYTES / (NT * 16), LPS = NPA + NPB;
+  static_assert(NPA >= 1 && NPB >= 1, "tile too small for the thread count");
+  static_assert((NS - 2) * LPS <= 63, "vmcnt immediate out of range");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  // XCD-aware, L2-friendly tile order.  Blocks b and b+8 share an XCD (private 4 MiB L2): give each XCD a
+  // contiguous run of ids (bijective remap), and number the tiles in column strips 4 n-tiles wide so that the
+  // ~32 workgroups an XCD runs concurrently form an (8 m) x (4 n) block: 12 operand panels feed 32 tiles.
+  const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int ntm = nwg / ntn;
+  const int strip = wg / (4 * ntm), sw = (ntn - strip * 4) < 4 ? (ntn - strip * 4) : 4;
+  const int within = wg - strip * 4 * ntm;
+  const int64_t z = blockIdx.y;
+  const int64_t m0 = (int64_t)(within / sw) * BM, n0 = (int64_t)(strip * 4 + within % sw) * BN;
+
+  DmaUnits<BM, AKM, NPA, NT> ua;
+  DmaUnits<BN, BKM, NPB, NT> ub;
+  ua.init(p.A + z * p.sA * 2, p.lda, m0, p.M, tid);
+  ub.init(p.B + z * p.sB * 2, p.ldb, n0, p.N, tid);
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int64_t nkt = (p.K + 63) / 64;
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) {
+    ua.issue(s, p.K, smem + s * STAGE, wave);
+    ub.issue(s, p.K, smem + s * STAGE + A_BYTES, wave);
+  }
+  int slot = 0, fill = NS - 1;
+  for (int64_t t = 0; t < nkt; ++t) {
+    // K-tile t has landed for this wave's own DMA once at most (NS-2) younger stages are still in flight
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPS) : "memory");
+    __builtin_amdgcn_s_barrier();      // ... and for everybody's; everybody is also done reading slot `fill`
+    asm volatile("" ::: "memory");     // s_barrier is IntrNoMem: keep the LDS reads / DMA issue below it
+    ua.issue(t + NS - 1, p.K, smem + fill * STAGE, wave);
+    ub.issue(t + NS - 1, p.K, smem + fill * STAGE + A_BYTES, wave);
+    const char* cA = smem + slot * STAGE;
+    const char* cB = cA + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fa[MI], fb[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fa[i] = frag_bf16<BM, AKM>(cA, wm * WTM + i * 16, kk, lane);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) fb[j] = frag_bf16<BN, BKM>(cB, wn * WTN + j * 16, kk, lane);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = mfma_bf16_k32(fb[j], fa[i], acc[i][j]);
+    }
+    slot = (slot + 1 == NS) ? 0 : slot + 1;
+    fill = (fill + 1 == NS) ? 0 : fill + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's trailing (zero page) DMAs must land before LDS is released
+
+  const int g = lane >> 4, li = lane & 15;
+  const DropKey dk = make_drop((p.epi & GSTVD_EPI_DROPOUT) ? p.p : 0.f, p.site, p.rng);
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+      gemm_epilogue_tile<bf16, OT>(p, dk, acc[i][j], z, m0 + wm * WTM + i * 16 + li, n0 + wn * WTN + j * 16 + 4 * g);
+}
+
+template <typename OT, int BM, int BN, int WM, int WN, bool AKM, bool BKM, int NS>
+static int dma_launch(const GemmP& p, int64_t batch, hipStream_t s) {
+  constexpr int lds = NS * (BM + BN) * 128;
+  auto k = gemm_dma_kernel<OT, BM, BN, WM, WN, AKM, BKM, NS>;
+  static int attr_rc = ensure_lds(k, lds);
+  if (attr_rc) return attr_rc;
+  const int ntm = (int)((p.M + BM - 1) / BM), ntn = (int)((p.N + BN - 1) / BN);
+  hipLaunchKernelGGL(k, dim3((unsigned)(ntm * ntn), (unsigned)batch), dim3(WM * WN * 64), lds, s, p, ntn, ntm * ntn);
+  GSTVD_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename OT, bool AKM, bool BKM>
+static int dma_layout(const GemmP& p, int64_t batch, hipStream_t s) {
+  // GSTVD_GEMM_VARIANT (read once) selects a main-loop variant for tuning runs: 0 = default policy,
+  // 1 = always the register-staged kernel of gemm.hip, 2 = 4-wave 128x128 ring, 3 = 64x64 ring with 6 stages
+  static const int variant = [] { const char* e = getenv("GSTVD_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
+  if (variant == 1) return GSTVD_E_UNSUPPORTED;
+  const int64_t big = ((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
+  if (p.M >= 256 && p.N >= 128 && big >= 96) {
+    if (variant == 2) return dma_launch<OT, 128, 128, 2, 2, AKM, BKM, 4>(p, batch, s);
+    return dma_launch<OT, 128, 128, 2, 4, AKM, BKM, 4>(p, batch, s);
+  }
+  if (variant == 3) return dma_launch<OT, 64, 64, 2, 2, AKM, BKM, 6>(p, batch, s);
+  return dma_launch<OT, 64, 64, 2, 2, AKM, BKM, 4>(p, batch, s);
+}
+
+template <typename OT>
+static int dma_out(const GemmP& p, int64_t batch, int akm, int bkm, hipStream_t s) {
+  if (!akm && !bkm) return dma_layout<OT, false, false>(p, batch, s);
+  if (!akm && bkm) return dma_layout<OT, false, true>(p, batch, s);
+  if (akm && bkm) return dma_layout<OT, true, true>(p, batch, s);
+  return dma_layout<OT, true, false>(p, batch, s);
+}
+
+int gemm_dma_dispatch(const GemmP& p, int64_t batch, int akm, int bkm, int out_f32, hipStream_t s) {
+  return out_f32 ? dma_out<float>(p, batch, akm, bkm, s) : dma_out<bf16>(p, batch, akm, bkm, s);
+}

@@ -12,7 +12,7 @@ struct LnP {
   float *dword, *dpos, *dtt, *dtt_ext;
 };
 
-constexpr int LN_BWD_RPB = 16;   // rows per block in backward (4 waves x 4 rows)
+constexpr int LN_BWD_RPB = 8;    // rows per block in backward (4 waves x 2 rows)
 
 // h = pre-LayerNorm row, 4 elements starting at column c
 template <typename T, int MODE>
@@ -93,55 +93,68 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(gstvd_ln_t f) {
   }
 }
 
+// Backward: a block owns LN_BWD_RPB = 8 consecutive rows, each wave two of them.  Both rows' loads are issued
+// before any reduction (memory-level parallelism), column partial sums stay in registers and are combined
+// across the 4 waves through LDS with plain stores (no LDS atomics), one [3][H] slab per block goes to HBM.
 template <typename T, int MODE, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(LnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* red = (float*)smem;                   // [3][H]
+  float* red = (float*)smem;                   // [4 waves][3][H]
   const gstvd_ln_t& f = p.f;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int H = (int)f.H;
-  for (int i = threadIdx.x; i < 3 * H; i += 256) red[i] = 0.f;
   const DropKey dpre = make_drop(MODE == GSTVD_LN_RESID ? f.p_pre : 0.f, f.site_pre, f.rng);
   const DropKey dpost = make_drop(f.p_post, f.site_post, f.rng);
   f32x4 ag[NV], ab[NV], ax[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) ag[i] = ab[i] = ax[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int j = 0; j < LN_BWD_RPB / 4; ++j) {
-    const int64_t row = (int64_t)blockIdx.x * LN_BWD_RPB + wave + 4 * j;
-    if (row >= f.M) break;
-    int64_t id = 0, tpos = 0, seg = 0;
-    float locrow[5] = {0, 0, 0, 0, 0};
-    if (MODE == GSTVD_LN_EMBED) { id = f.ids[row]; tpos = row % f.T; seg = f.segs ? f.segs[row] : 0; }
-    if (MODE == GSTVD_LN_IMAGE) {
+  const int64_t row0 = (int64_t)blockIdx.x * LN_BWD_RPB + wave * 2;
+  f32x4 xh[2][NV], gy[2][NV], dyv[2][NV];
+  float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f}, rstd[2] = {0.f, 0.f};
+  int64_t id[2] = {0, 0}, tpos[2] = {0, 0}, seg[2] = {0, 0};
+  bool rv[2];
 #pragma unroll
-      for (int q = 0; q < 5; ++q) locrow[q] = f.loc[row * 5 + q];
+  for (int j = 0; j < 2; ++j) {
+    const int64_t row = row0 + j;
+    rv[j] = row < f.M;
+    float locrow[5] = {0, 0, 0, 0, 0};
+    float mean = 0.f;
+    if (rv[j]) {
+      if (MODE == GSTVD_LN_EMBED) { id[j] = f.ids[row]; tpos[j] = row % f.T; seg[j] = f.segs ? f.segs[row] : 0; }
+      if (MODE == GSTVD_LN_IMAGE) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) locrow[q] = f.loc[row * 5 + q];
+      }
+      mean = f.mean[row];
+      rstd[j] = f.rstd[row];
     }
-    const float mean = f.mean[row], rstd = f.rstd[row];
-    f32x4 xh[NV], gy[NV], dyv[NV];
-    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = lane * 4 + i * 256;
-      xh[i] = gy[i] = dyv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (c < H) {
-        f32x4 h = ln_prologue<T, MODE>(f, row, c, dpre, id, tpos, seg, locrow);
-        xh[i] = (h - mean) * rstd;
-        dyv[i] = ld4((const T*)p.dy + row * p.lddy + c) * drop_factor4(dpost, (uint64_t)(row * f.H + c));
-        gy[i] = dyv[i] * *(const f32x4*)(f.gamma + c);
-        s1 += gy[i][0] + gy[i][1] + gy[i][2] + gy[i][3];
-        f32x4 t = gy[i] * xh[i];
-        s2 += t[0] + t[1] + t[2] + t[3];
+      xh[j][i] = gy[j][i] = dyv[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (rv[j] && c < H) {
+        f32x4 h = ln_prologue<T, MODE>(f, row, c, dpre, id[j], tpos[j], seg[j], locrow);
+        xh[j][i] = (h - mean) * rstd[j];
+        dyv[j][i] = ld4((const T*)p.dy + row * p.lddy + c) * drop_factor4(dpost, (uint64_t)(row * f.H + c));
+        gy[j][i] = dyv[j][i] * *(const f32x4*)(f.gamma + c);
+        s1[j] += gy[j][i][0] + gy[j][i][1] + gy[j][i][2] + gy[j][i][3];
+        f32x4 t = gy[j][i] * xh[j][i];
+        s2[j] += t[0] + t[1] + t[2] + t[3];
       }
     }
-    const float c1 = wave_sum(s1) / (float)H, c2 = wave_sum(s2) / (float)H;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int64_t row = row0 + j;
+    const float c1 = wave_sum(s1[j]) / (float)H, c2 = wave_sum(s2[j]) / (float)H;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = lane * 4 + i * 256;
-      if (c < H) {
-        f32x4 dh = (gy[i] - c1 - xh[i] * c2) * rstd;
-        ag[i] += dyv[i] * xh[i];
-        ab[i] += dyv[i];
+      if (rv[j] && c < H) {
+        f32x4 dh = (gy[j][i] - c1 - xh[j][i] * c2) * rstd[j];
+        ag[i] += dyv[j][i] * xh[j][i];
+        ab[i] += dyv[j][i];
         if (MODE == GSTVD_LN_RESID) {
           if (p.dres) st4((T*)p.dres + row * p.lddres + c, dh);
           f32x4 dx = dh * drop_factor4(dpre, (uint64_t)(row * f.H + c));
@@ -151,33 +164,34 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnP p) {
           st4((T*)p.dres + row * p.lddres + c, dh);
           ax[i] += dh;
         } else {
-          float* tg = (seg < f.type_vocab) ? p.dtt + seg * f.H : p.dtt_ext + (seg - f.type_vocab) * f.H;
+          float* tg = (seg[j] < f.type_vocab) ? p.dtt + seg[j] * f.H : p.dtt_ext + (seg[j] - f.type_vocab) * f.H;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            atomicAdd(p.dword + id * f.H + c + e, dh[e]);
-            atomicAdd(p.dpos + tpos * f.H + c + e, dh[e]);
+            atomicAdd(p.dword + id[j] * f.H + c + e, dh[e]);
+            atomicAdd(p.dpos + tpos[j] * f.H + c + e, dh[e]);
             atomicAdd(tg + c + e, dh[e]);
           }
         }
       }
     }
   }
-  __syncthreads();
+  float* mine = red + (int64_t)wave * 3 * H;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = lane * 4 + i * 256;
     if (c < H) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        atomicAdd(red + c + e, ag[i][e]);
-        atomicAdd(red + H + c + e, ab[i][e]);
-        if (MODE != GSTVD_LN_EMBED) atomicAdd(red + 2 * H + c + e, ax[i][e]);
-      }
+      *(f32x4*)(mine + c) = ag[i];
+      *(f32x4*)(mine + H + c) = ab[i];
+      *(f32x4*)(mine + 2 * H + c) = ax[i];
     }
   }
   __syncthreads();
   float* out = p.partial + (int64_t)blockIdx.x * 3 * H;
-  for (int i = threadIdx.x; i < 3 * H; i += 256) out[i] = red[i];
+  for (int i = threadIdx.x * 4; i < 3 * H; i += 1024) {
+    f32x4 a = *(const f32x4*)(red + i) + *(const f32x4*)(red + 3 * H + i) + *(const f32x4*)(red + 6 * H + i) +
+              *(const f32x4*)(red + 9 * H + i);
+    *(f32x4*)(out + i) = a;
+  }
 }
 
 // out_j[c] (+)= sum_b partial[b][j][c]; block = 64 columns x 4 row groups
@@ -257,6 +271,31 @@ __global__ __launch_bounds__(256) void locgrad_kernel(const T* dh, int64_t lddh,
   for (int j = 0; j < 5; ++j) atomicAdd(dw + h * 5 + j, a[j]);
 }
 
+// All pending column reductions of a backward pass in ONE launch: block b serves the 64-column slice
+// (b - blk0) of the entry that contains it (binary search over the entries' first-block offsets).
+__global__ __launch_bounds__(256) void colsum_batched_kernel(const gstvd_colsum_entry_t* tab, int nent) {
+  __shared__ float red[4][64];
+  int lo = 0, hi = nent - 1;
+  const int b = blockIdx.x;
+  while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (tab[mid].blk0 <= b) lo = mid; else hi = mid - 1; }
+  const gstvd_colsum_entry_t e = tab[lo];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int64_t col = (int64_t)(b - e.blk0) * 64 + cl, W = (int64_t)e.nvec * e.H;
+  float a = 0.f;
+  if (col < W) {
+    const float* src = e.partial + col;
+    for (int64_t k = rg; k < e.nblk; k += 4) a += src[k * e.stride];
+  }
+  red[rg][cl] = a;
+  __syncthreads();
+  if (rg == 0 && col < W) {
+    a = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+    const int64_t j = col / e.H, c = col % e.H;
+    float* o = e.out[j];
+    if (o) o[c] = e.accumulate[j] ? o[c] + a : a;
+  }
+}
+
 // ---- host side -------------------------------------------------------------------------------------
 static int ln_check(const gstvd_ln_t* p) {
   if (!p) return GSTVD_E_NULL;
@@ -299,7 +338,11 @@ extern "C" int64_t gstvd_ln_bwd_blocks(int64_t M) { return (M + LN_BWD_RPB - 1) 
 template <typename T, int MODE>
 static int ln_bwd_nv(const LnP& p, hipStream_t s) {
   dim3 grid((unsigned)gstvd_ln_bwd_blocks(p.f.M)), block(256);
-  size_t lds = (size_t)3 * p.f.H * sizeof(float);
+  size_t lds = (size_t)4 * 3 * p.f.H * sizeof(float);
+  if (lds > 48 * 1024) {
+    static int rc8 = (int)hipFuncSetAttribute((const void*)ln_bwd_kernel<T, MODE, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 3 * 2048 * 4);
+    if (rc8) return rc8;
+  }
   if (p.f.H <= 256) hipLaunchKernelGGL((ln_bwd_kernel<T, MODE, 1>), grid, block, lds, s, p);
   else if (p.f.H <= 768) hipLaunchKernelGGL((ln_bwd_kernel<T, MODE, 3>), grid, block, lds, s, p);
   else if (p.f.H <= 1024) hipLaunchKernelGGL((ln_bwd_kernel<T, MODE, 4>), grid, block, lds, s, p);
@@ -334,6 +377,30 @@ extern "C" int gstvd_colsum_partials(const float* partial, int64_t nblk, int64_t
   if (nblk <= 0 || nvec <= 0 || nvec > 3 || H <= 0) return GSTVD_E_SHAPE;
   dim3 grid((unsigned)((nvec * H + 63) / 64));
   hipLaunchKernelGGL(colsum_partials_kernel, grid, dim3(256), 0, (hipStream_t)stream, partial, nblk, nvec, H, out0, out1, out2, accumulate);
+  GSTVD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gstvd_colsum_batched(const gstvd_colsum_entry_t* table_dev, int64_t nent, int64_t total_blocks, gstvd_stream_t stream) {
+  if (!table_dev) return GSTVD_E_NULL;
+  if (nent <= 0 || total_blocks <= 0) return GSTVD_E_SHAPE;
+  hipLaunchKernelGGL(colsum_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, table_dev, (int)nent);
+  GSTVD_LAUNCH_CHECK();
+  return 0;
+}
+
+// stage 1 only of a plain column sum: scratch[slab][N] (slab = 64 rows); finish with gstvd_colsum_batched / _partials
+extern "C" int gstvd_colsum_slabs(const void* x, int64_t ldx, int64_t M, int64_t N, int32_t dtype, float* scratch,
+                                  int64_t scratch_elems, gstvd_stream_t stream) {
+  if (!x || !scratch) return GSTVD_E_NULL;
+  if (M <= 0 || N <= 0 || (N % 4)) return GSTVD_E_SHAPE;
+  const int64_t nslab = (M + 63) / 64;
+  if (scratch_elems < nslab * N) return GSTVD_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)((N + 255) / 256), (unsigned)nslab);
+  if (dtype == GSTVD_BF16) hipLaunchKernelGGL(colsum_slab_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)x, ldx, M, N, scratch);
+  else if (dtype == GSTVD_F32) hipLaunchKernelGGL(colsum_slab_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ldx, M, N, scratch);
+  else return GSTVD_E_DTYPE;
   GSTVD_LAUNCH_CHECK();
   return 0;
 }

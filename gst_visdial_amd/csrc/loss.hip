@@ -119,7 +119,8 @@ __global__ void dropout_mask_kernel(float* out, int64_t n, float p, uint32_t sit
   if (i < n) out[i] = drop_factor(dk, (uint64_t)i);
 }
 
-// AdamW: pytorch_transformers==1.2.0 optimization.AdamW.step (train_gen.py:16,247)
+// AdamW: pytorch_transformers==1.2.0 optimization.AdamW.step (train_gen.py:16,247).  Segments are 4-element aligned
+// (the flat layout aligns every tensor to 64 elements), so one lookup serves a 16-byte vector.
 __global__ __launch_bounds__(256) void adamw_kernel(float* param, const float* grad, float* m, float* v, bf16* shadow, int64_t n,
                                                     const int64_t* seg_end, const float* hp, int64_t nseg, float b1, float b2,
                                                     float eps, const float* step, float gscale) {
@@ -127,19 +128,38 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* param, const float* g
   if (i >= n) return;
   int64_t lo = 0, hi = nseg - 1;                       // first segment whose end > i
   while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (seg_end[mid] > i) hi = mid; else lo = mid + 1; }
+  const float lr = hp[2 * lo], wd = hp[2 * lo + 1];
+  if (lr == 0.f) return;                               // padding / frozen segment
   const float t = step[0];
   const float bc = sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
+  if (i + 3 < n && seg_end[lo] >= i + 4) {
+    const f32x4 g4 = *(const f32x4*)(grad + i) * gscale;
+    const f32x4 m4 = *(const f32x4*)(m + i) * b1 + g4 * (1.f - b1);
+    const f32x4 v4 = *(const f32x4*)(v + i) * b2 + g4 * g4 * (1.f - b2);
+    f32x4 p4 = *(const f32x4*)(param + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float pp = p4[e] - lr * bc * (m4[e] / (sqrtf(v4[e]) + eps));
+      if (wd > 0.f) pp += -lr * wd * pp;
+      p4[e] = pp;
+    }
+    *(f32x4*)(m + i) = m4;
+    *(f32x4*)(v + i) = v4;
+    *(f32x4*)(param + i) = p4;
+    if (shadow) st4(shadow + i, p4);
+    return;
+  }
   int64_t seg = lo;
   for (int e = 0; e < 4 && i + e < n; ++e) {
     const int64_t k = i + e;
     while (seg < nseg - 1 && seg_end[seg] <= k) ++seg;
-    const float lr = hp[2 * seg], wd = hp[2 * seg + 1];
+    const float lr_ = hp[2 * seg], wd_ = hp[2 * seg + 1];
     const float gg = grad[k] * gscale;
     const float mm = m[k] * b1 + (1.f - b1) * gg;
     const float vv = v[k] * b2 + (1.f - b2) * gg * gg;
     m[k] = mm; v[k] = vv;
-    float pp = param[k] - lr * bc * (mm / (sqrtf(vv) + eps));
-    if (wd > 0.f) pp += -lr * wd * pp;
+    float pp = param[k] - lr_ * bc * (mm / (sqrtf(vv) + eps));
+    if (wd_ > 0.f) pp += -lr_ * wd_ * pp;
     param[k] = pp;
     if (shadow) shadow[k] = (bf16)pp;
   }

@@ -25,7 +25,8 @@ class GradSync(object):
         self.handles = []
         self.hi = None
         self.slices = []                  # (lo, hi) log of the last step, for tests / DESIGN.md
-        engine.grad_hook = self.hook
+        if self.world > 1:
+            engine.grad_hook = self.hook
 
     def begin(self):
         self.hi = self.engine.flat.n_live

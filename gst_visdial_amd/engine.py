@@ -286,6 +286,7 @@ class Engine(object):
             self.arena = Arena(device)
             self.rng = ops.Rng(device, seed=int(self.model.params.get("amd_seed", 0)))
             self.anchor = torch.zeros(1, device=device, requires_grad=True)
+            self.colsums = ops.ColsumBatch(device)
         self.flat.refresh_shadow()
 
     def _bind_views(self):
@@ -325,7 +326,11 @@ class Engine(object):
     def mark(self, key):
         if self.rec and self.grad_hook is not None:
             off = self.flat.marks[key]
-            self.tape.append(lambda: self.grad_hook(off))
+            self.tape.append(lambda: self._hook(off))
+
+    def _hook(self, off):
+        self.colsums.flush()          # bias / LayerNorm gradients of the finished region must be final first
+        self.grad_hook(off)
 
     # ------------------------------------------------------------------------------------------ ops
     def lin(self, x, w, b, N, K, gelu=False, need_dx=True):
@@ -345,8 +350,10 @@ class Engine(object):
         ops.gemm(dy, x.t, gw, N, K, M, a_km=True, b_km=True, addend=gw if acc else None)
         if not y.bias_done:
             gb, accb = self.grad_slot(b)
-            scratch = self.vec(((M + 63) // 64) * N)
-            ops.colsum(dy, M, N, gb, scratch, accb)
+            nslab = (M + 63) // 64
+            scratch = self.vec(nslab * N)
+            ops.colsum_slabs(dy, M, N, scratch)
+            self.colsums.add(scratch, (gb, None, None), nslab, N, N, 1, (accb, False, False))
         if need_dx:
             add = x.g
             if x.g is None:
@@ -365,23 +372,15 @@ class Engine(object):
         return y
 
     def _colsums(self, partial, nblk, H, names):
-        """Reduce LN-backward partials into up to three gradient slots (None = skip)."""
+        """Queue the reduction of LN-backward partials into up to three gradient slots (None = skip)."""
         outs, accs = [], []
         for n in names:
             if n is None:
-                outs.append(None); accs.append(None)
+                outs.append(None); accs.append(False)
             else:
                 gv, a = self.grad_slot(n)
                 outs.append(gv); accs.append(a)
-        flags = set(a for a in accs if a is not None)
-        if len(flags) <= 1:
-            ops.colsum_partials(partial, nblk, 3, H, outs[0], outs[1], outs[2], flags.pop() if flags else False)
-        else:
-            for j in range(3):
-                if outs[j] is not None:
-                    o = [None, None, None]
-                    o[j] = outs[j]
-                    ops.colsum_partials(partial, nblk, 3, H, o[0], o[1], o[2], accs[j])
+        self.colsums.add(partial, outs, nblk, 3 * H, H, 3, accs)
 
     def _ln_bwd(self, kw, x, res, y, g, b, H, bias_name):
         M = x.M
@@ -666,12 +665,14 @@ class Engine(object):
                 elif p.grad.data_ptr() != gv.data_ptr():
                     gv.copy_(p.grad)
         self.written = set()
+        self.colsums.reset()
         logits = st["logits"]
         logits.g = self.buf(st["Md"], flat.Vp)
         gs = gloss.reshape(1).float().contiguous() if gloss is not None else None
         ops.ce_bwd(logits.t, st["lab"], st["lse"], st["stats"], gs, True, st["Md"], st["V"], logits.g, ignore_index=st["pad"])
         for fn in reversed(st["tape"]):
             fn()
+        self.colsums.flush()
         if self.grad_hook is not None:
             self.grad_hook(0)
         for p, gv in zip(flat.live, flat.grad_views):

@@ -45,10 +45,12 @@ class Profiler(object):
     def __exit__(self, *a):
         Profiler.active = None
 
-    def summary(self):
+    def summary(self, by_shape=False):
         torch.cuda.synchronize()
         agg = {}
-        for tag, flops, nbytes, e0, e1 in self.records:
+        for tag, flops, nbytes, e0, e1, detail in self.records:
+            if by_shape and detail is not None:
+                tag = "%s %s" % (tag, "x".join(str(d) for d in detail))
             a = agg.setdefault(tag, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
             a["launches"] += 1
             a["ms"] += e0.elapsed_time(e1)
@@ -65,12 +67,12 @@ def _prof_begin():
     return e
 
 
-def _prof_end(e0, tag, flops=0.0, nbytes=0.0):
+def _prof_end(e0, tag, flops=0.0, nbytes=0.0, detail=None):
     if e0 is None:
         return
     e1 = torch.cuda.Event(enable_timing=True)
     e1.record()
-    Profiler.active.records.append((tag, flops, nbytes, e0, e1))
+    Profiler.active.records.append((tag, flops, nbytes, e0, e1, detail))
 
 
 def gemm_tag(dtype_in, a_km, b_km, M, N, batch):
@@ -125,7 +127,7 @@ def gemm(A, B, C_out, M, N, K, *, a_km=False, b_km=False, bias=None, addend=None
     e0 = _prof_begin()
     L.check("gstvd_gemm", lib.gstvd_gemm(C.byref(d), _stream()))
     _prof_end(e0, gemm_tag(d.dtype_in, a_km, b_km, M, N, batch), 2.0 * M * N * K * batch,
-              float(batch) * ((M * K + N * K) * A.element_size() + M * N * C_out.element_size()))
+              float(batch) * ((M * K + N * K) * A.element_size() + M * N * C_out.element_size()), (M, N, K, batch))
     return C_out
 
 
@@ -187,6 +189,62 @@ def colsum(x, M, N, out, scratch, accumulate):
     L.check("gstvd_colsum", lib.gstvd_colsum(_p(x), x.stride(-2), M, N, dt(x), _p(out), _p(scratch), scratch.numel(),
                                              int(accumulate), _stream()))
     _prof_end(e0, "colsum", 0.0, float(M) * N * x.element_size())
+
+
+def colsum_slabs(x, M, N, scratch):
+    lib = L.load()
+    e0 = _prof_begin()
+    L.check("gstvd_colsum_slabs", lib.gstvd_colsum_slabs(_p(x), x.stride(-2), M, N, dt(x), _p(scratch), scratch.numel(), _stream()))
+    _prof_end(e0, "colsum_slabs", 0.0, float(M) * N * x.element_size())
+
+
+class ColsumBatch(object):
+    """Collects column reductions (LayerNorm-backward partials, bias-gradient slabs) and runs them in ONE launch.
+    The device table is rebuilt only when the (static, arena-addressed) entry list changes."""
+
+    def __init__(self, device):
+        self.device = device
+        self.entries = []            # (partial_ptr, (out0,out1,out2 ptrs), nblk, stride, H, nvec, (acc0,acc1,acc2))
+        self.targets = set()
+        self.cache = {}
+
+    def add(self, partial, outs, nblk, stride, H, nvec, accs):
+        ptrs = [o.data_ptr() for o in outs if o is not None]
+        if any(p in self.targets for p in ptrs):      # same output twice (shared embedding LayerNorm): keep launch order
+            self.flush()
+        self.targets.update(ptrs)
+        self.entries.append((partial.data_ptr(), tuple(o.data_ptr() if o is not None else 0 for o in outs), nblk, stride, H,
+                             nvec, tuple(int(bool(a)) for a in accs)))
+
+    def reset(self):
+        self.entries, self.targets = [], set()
+
+    def flush(self):
+        if not self.entries:
+            return
+        key = tuple(self.entries)
+        hit = self.cache.get(key)
+        if hit is None:
+            arr = (L.ColsumEntry * len(key))()
+            blk = 0
+            for e, (pp, outs, nblk, stride, H, nvec, accs) in zip(arr, key):
+                e.partial = pp
+                for j in range(3):
+                    e.out[j] = outs[j] or None
+                    e.accumulate[j] = accs[j]
+                e.nblk, e.stride, e.H, e.nvec, e.blk0 = nblk, stride, H, nvec, blk
+                blk += (nvec * H + 63) // 64
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            hit = (host.to(self.device), len(key), blk)
+            if len(self.cache) > 64:
+                self.cache.clear()
+            self.cache[key] = hit
+        tab, n, blocks = hit
+        lib = L.load()
+        e0 = _prof_begin()
+        L.check("gstvd_colsum_batched", lib.gstvd_colsum_batched(tab.data_ptr(), n, blocks, _stream()))
+        _prof_end(e0, "colsum_batched", 0.0, 0.0)
+        self.entries, self.targets = [], set()
 
 
 def locgrad(dh, loc, M, H, dw_loc, accumulate):

@@ -114,6 +114,19 @@ int gstvd_ln_bwd(const gstvd_ln_bwd_t* p, gstvd_stream_t s);
 int gstvd_colsum_partials(const float* partial, int64_t nblk, int64_t nvec, int64_t H,
                           float* out0, float* out1, float* out2, int32_t accumulate, gstvd_stream_t s);
 
+/* Batched form: every pending column reduction of a backward pass in ONE launch.  `table_dev` is a device
+ * array of entries; entry i owns blocks [blk0_i, blk0_{i+1}) of the grid, one block per 64 output columns
+ * of its nvec*H wide row; out_j[c] (+)= sum_{k<nblk} partial[k*stride + j*H + c]. */
+typedef struct {
+  const float* partial; float* out[3];
+  int64_t nblk, stride, H;
+  int32_t nvec, accumulate[3], blk0;
+} gstvd_colsum_entry_t;
+int gstvd_colsum_batched(const gstvd_colsum_entry_t* table_dev, int64_t nent, int64_t total_blocks, gstvd_stream_t s);
+/* stage 1 of a plain column sum: scratch[slab, N] = per-64-row-slab sums of x[M, N] (reduce with the batched form) */
+int gstvd_colsum_slabs(const void* x, int64_t ldx, int64_t M, int64_t N, int32_t dtype, float* scratch,
+                       int64_t scratch_elems, gstvd_stream_t s);
+
 /* out[c] (+)= sum_m x[m, c]   (bias gradients of QKV / FFN-up projections) */
 int gstvd_colsum(const void* x, int64_t ldx, int64_t M, int64_t N, int32_t dtype, float* out,
                  float* scratch, int64_t scratch_elems, int32_t accumulate, gstvd_stream_t s);
