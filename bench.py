@@ -105,8 +105,9 @@ def cpu_baseline(model, T, R, U, F, V, rows=2):
 
     one(1, 16)                                     # thread-pool / allocator warm-up (untimed)
     n, dt = 1, one(1, T)
-    if dt < 8.0:
-        n, dt = rows, one(rows, T)
+    if dt < 8.0:                                   # size the real sample for ~15 s of CPU work (cap 32 rows)
+        n = max(2, min(32, int(15.0 / max(dt, 1e-3))))
+        dt = one(n, T)
     return {"value": n / dt, "unit": "dialog-rounds/sec", "cores": threads, "kind": "port",
             "sample": "%d row(s) x 1 train step (fwd+loss+bwd, fp32, T=%d R=%d U=%d) of oracle/vd_oracle.py on %d threads; %.1f s"
                       % (n, T, R, U, threads, dt)}

@@ -1,0 +1,78 @@
+"""Data-parallel gradient sync (gst_visdial_amd/dp.py) on CPU with the gloo backend, world_size 2:
+bucketed, backward-ordered all-reduce of the flat gradient buffer == sum over ranks; slices tile [0, n) exactly once."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+class _Flat:
+    def __init__(self, n, rank):
+        g = torch.Generator().manual_seed(100 + rank)
+        self.G = torch.randn(n, generator=g)
+        self.n_live = n
+
+
+class _Engine:
+    def __init__(self, n, rank):
+        self.flat = _Flat(n, rank)
+        self.grad_hook = None
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, marks, bucket, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gst_visdial_amd.dp import GradSync
+    eng = _Engine(n, rank)
+    expect = sum(_Flat(n, r).G for r in range(world))
+    sync = GradSync(eng, bucket_elems=bucket)
+    assert eng.grad_hook is not None
+    sync.begin()
+    for off in marks:                       # backward finishes the flat buffer from the end to the start
+        eng.grad_hook(off)
+    sync.finish()
+    ok = torch.allclose(eng.flat.G, expect, atol=1e-6)
+    q.put((rank, ok, sync.slices))
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_world2():
+    n, bucket = 10000, 3000
+    marks = [9000, 8200, 7000, 6400, 3000, 2500, 64, 0]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, marks, bucket, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, slices in res:
+        assert ok, "rank %d: all-reduced gradients differ from the sum over ranks" % rank
+        # slices are contiguous, descending, cover [0, n) exactly once, and every bucket but the last is >= bucket
+        assert slices[0][1] == n and slices[-1][0] == 0
+        for (lo, hi), (lo2, hi2) in zip(slices, slices[1:]):
+            assert hi2 == lo
+        assert all(hi - lo >= bucket for lo, hi in slices[:-1])
+        assert len(slices) < len(marks)
+
+
+def test_single_process_installs_no_hook():
+    from gst_visdial_amd.dp import GradSync
+    eng = _Engine(100, 0)
+    s = GradSync(eng)
+    assert eng.grad_hook is None
+    s.begin(); s.finish()

@@ -1,0 +1,156 @@
+"""Host-side logic of the product that runs without a GPU: the row-selection driver (train_gen.forward's index
+work, bit-exact against the oracle's restatement), the token-id decoding filters (bit-exact against the golden
+vectors produced by the reference), the LR schedule, the flat parameter plan and the 861-key checkpoint layout."""
+import json
+import os
+import tempfile
+
+import torch
+
+from conftest import GOLDEN, load_npz
+from oracle import vd_oracle as O
+
+
+def _dialog_batch(B=3, rounds=4, T=12, U=6, R=5, F=8, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    b = dict(enc_input_ids=torch.randint(1, 50, (B, rounds, 1, T), generator=g),
+             enc_segments=torch.randint(0, 2, (B, rounds, 1, T), generator=g),
+             enc_att_mask=torch.ones(B, rounds, 1, T),
+             dec_input_ids=torch.randint(1, 50, (B, rounds, 1, U), generator=g),
+             dec_att_mask=torch.ones(B, rounds, 1, U),
+             dec_labels=torch.randint(1, 50, (B, rounds, 1, U), generator=g),
+             enc_image_feat=torch.randn(B, R, F, generator=g), enc_image_loc=torch.rand(B, R, 5, generator=g),
+             enc_image_mask=torch.ones(B, R))
+    b["dec_labels"][0, 1] = 0            # rows filtered by -select_data carry all-zero labels
+    b["dec_labels"][2, 3] = 0
+    return b
+
+
+def test_select_rows_matches_reference_semantics():
+    from gst_visdial_amd.step import select_rows
+    b = _dialog_batch()
+    params = dict(mode="vd_train", batch_size=7)
+    rows, idx = select_rows(b, params, generator=torch.Generator().manual_seed(1))
+    labels_flat = b["dec_labels"].reshape(-1, b["dec_labels"].shape[-1])
+    cand = O.candidate_rows(labels_flat)
+    assert idx.shape == (7,) and torch.all(cand[idx] == 1)          # only rows with a non-zero label row are drawn
+    # same draw as the reference's torch.multinomial on the same candidate weights and generator state
+    ref_idx = torch.multinomial(cand, 7, replacement=True, generator=torch.Generator().manual_seed(1))
+    assert torch.equal(idx, ref_idx)
+    # the reference expands image tensors 10x on the host then gathers rows (train_gen.py:311-321,45-116)
+    rounds = b["enc_input_ids"].shape[1]
+    exp = {k: v for k, v in b.items()}
+    for k in ("enc_image_feat", "enc_image_loc", "enc_image_mask"):
+        v = b[k]
+        exp[k] = v.unsqueeze(1).unsqueeze(1).expand(v.shape[0], rounds, 1, *v.shape[1:]).contiguous()
+    ref = O.flatten_and_gather(exp, idx)
+    for k in ("enc_input_ids", "enc_segments", "enc_att_mask", "dec_input_ids", "dec_att_mask", "dec_labels",
+              "enc_image_feat", "enc_image_loc", "enc_image_mask"):
+        assert torch.equal(rows[k], ref[k]), k
+    rows2, _ = select_rows(exp, params, sample_indices=idx)          # expanded (reference) layout gives the same rows
+    for k in rows:
+        assert torch.equal(rows[k], rows2[k]), k
+
+
+def test_select_rows_eval_keeps_every_row_in_order():
+    from gst_visdial_amd.step import select_rows
+    b = _dialog_batch()
+    rows, idx = select_rows(b, dict(mode="vd_eval_val", batch_size=7))
+    assert torch.equal(idx, torch.arange(12)) and "dec_labels" not in rows
+    assert torch.equal(rows["enc_input_ids"], b["enc_input_ids"].reshape(12, -1))
+
+
+def test_decoding_filters_bit_exact(utils_golden):
+    from gst_visdial_amd import decoding as D
+    u = utils_golden
+
+    def fin(t):
+        return torch.where(torch.isinf(t), torch.full_like(t, -1e30), t)
+
+    assert torch.equal(fin(D.batch_top_k_top_p_sampling(u["logits"].clone(), top_k=5)), u["topk5"])
+    assert torch.equal(fin(D.batch_top_k_top_p_sampling(u["logits"].clone(), top_k=0, top_p=0.6)), u["topp06"])
+    assert torch.equal(fin(D.batch_ngram_blocking(u["logits"].clone(), u["hist"], u["dec"], 3)), u["ngram3"])
+    assert torch.equal(fin(D.batch_ngram_blocking(u["logits"].clone(), u["hist"], u["dec"], 2)), u["ngram2"])
+    s = torch.tensor([[5, 102, 7, 102], [1, 2, 3, 4], [102, 9, 9, 9]])
+    assert D.pad_after_eos(s, 102, 0).tolist() == [[5, 102, 0, 0], [1, 2, 3, 4], [102, 0, 0, 0]]
+
+
+def test_lr_schedule_matches_reference(utils_golden):
+    from gst_visdial_amd.optim import warmup_linear_nonzero
+    lrs = torch.tensor([warmup_linear_nonzero(s, 10, 40, 2e-5) for s in range(45)], dtype=torch.float64)
+    assert (lrs - utils_golden["lrs"].double()).abs().max().item() < 1e-12
+
+
+def _tiny_model():
+    from gst_visdial_amd.modules import VisualDialogEncoder, VisualDialogDecoder, EncoderDecoderModel
+    cfg = json.load(open(os.path.join(GOLDEN, "tiny_cfg.json")))
+    d = tempfile.mkdtemp()
+    json.dump(cfg["enc"], open(d + "/e.json", "w"))
+    json.dump(cfg["dec"], open(d + "/d.json", "w"))
+    params = dict(model_enc_config=d + "/e.json", model_dec_config=d + "/d.json", gpu_ids=[0], model="enc_dec_a",
+                  mode="vd_train", batch_size=3)
+    enc, dec = VisualDialogEncoder(params), VisualDialogDecoder(params)
+    return EncoderDecoderModel(params, enc, dec), enc, dec
+
+
+def test_state_dict_layout_and_aliasing(tiny_state):
+    model, enc, dec = _tiny_model()
+    assert set(model.state_dict().keys()) == set(tiny_state.keys())
+    w_before = dec.decoder.lm_head.decoder.weight
+    assert w_before is dec.decoder.bert.embeddings.word_embeddings.weight        # tied at construction
+    dec.decoder.bert.embeddings = enc.bert_pretrained.bert.embeddings            # train_gen.py:293
+    assert dec.decoder.lm_head.decoder.weight is w_before                        # ... and untied after the swap
+    assert dec.decoder.lm_head.decoder.weight is not enc.bert_pretrained.bert.embeddings.word_embeddings.weight
+    assert dec.decoder.lm_head.bias is dec.decoder.lm_head.decoder.bias
+    assert enc.bert_pretrained.cls.predictions.decoder.weight is enc.bert_pretrained.bert.embeddings.word_embeddings.weight
+    model.load_state_dict(tiny_state, strict=True)
+    assert model.decoder.config.eos_token_id == 102 and model.decoder.config.pad_token_id == 0
+
+
+def test_full_config_has_861_keys():
+    from gst_visdial_amd.config import bert_base_enc_config, bert_base_dec_config
+    from gst_visdial_amd import modules as M
+    d = tempfile.mkdtemp()
+    e, c = bert_base_enc_config(), bert_base_dec_config()
+    for k in ("hidden_size", "v_hidden_size", "bi_hidden_size"):          # same tree, thin tensors: fast on CPU
+        e[k] = 64
+    e.update(intermediate_size=64, v_intermediate_size=64, num_attention_heads=2, v_num_attention_heads=2,
+             bi_num_attention_heads=2, vocab_size=128, v_feature_size=32)
+    c.update(hidden_size=64, intermediate_size=64, num_attention_heads=2, vocab_size=128)
+    json.dump(e, open(d + "/e.json", "w")); json.dump(c, open(d + "/d.json", "w"))
+    params = dict(model_enc_config=d + "/e.json", model_dec_config=d + "/d.json", gpu_ids=[0], model="enc_dec_a", mode="vd_train")
+    enc, dec = M.VisualDialogEncoder(params), M.VisualDialogDecoder(params)
+    model = M.EncoderDecoderModel(params, enc, dec)
+    dec.decoder.bert.embeddings = enc.bert_pretrained.bert.embeddings
+    assert len(model.state_dict()) == 861
+
+
+def test_flat_plan_groups_and_dead_params(tiny_state):
+    from gst_visdial_amd.engine import FlatParams
+    model, enc, dec = _tiny_model()
+    dec.decoder.bert.embeddings = enc.bert_pretrained.bert.embeddings
+    fp = FlatParams(model, "bf16")
+    nog = set(json.load(open(os.path.join(GOLDEN, "tiny_nograd_keys.json"))))
+    names = {id(p): n for n, p in model.named_parameters()}
+    assert set(names[id(p)] for p in fp.dead) == nog                             # the 42 no-grad tensors of the reference
+    off, shape = fp.slots["t0.qkv.w"]
+    lay = enc.bert_pretrained.bert.encoder.layer[0].attention.self
+    assert shape == (3 * 64, 64)
+    assert [fp.placed[id(p)] for p in (lay.query.weight, lay.key.weight, lay.value.weight)] == [off, off + 4096, off + 8192]
+    assert fp.slots["dec.ckv.w"][1] == (2 * 2 * 64, 64) and fp.slots["lm.w"][1] == (320, 64)
+    offs = sorted(o for _, o in fp.items)
+    assert all(o % 4 == 0 for o in offs) and fp.n_live % 64 == 0
+    marks = [fp.marks[k] for k in [("t", 0), ("c", 0), "vlf", "dec", ("d", 0), "lm"]]
+    assert marks == sorted(marks)                                                # forward order == flat order
+
+
+def test_product_refuses_cpu():
+    import pytest
+    from gst_visdial_amd._lib import GstvdError
+    model, enc, dec = _tiny_model()
+    g = load_npz("tiny_train.npz")
+    with pytest.raises(GstvdError):
+        model(enc_image_features=g["in::enc_image_features"], enc_image_spatials=g["in::enc_image_spatials"],
+              enc_image_mask=g["in::enc_image_mask"], enc_input_ids=g["in::enc_input_ids"], enc_segments=g["in::enc_segments"],
+              enc_attention_mask=g["in::enc_attention_mask"], dec_input_ids=g["in::dec_input_ids"],
+              dec_attention_mask=g["in::dec_attention_mask"], dec_labels=g["in::dec_labels"])
