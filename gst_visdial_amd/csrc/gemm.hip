@@ -149,7 +149,9 @@ extern "C" int gstvd_gemm(const gstvd_gemm_t* g, gstvd_stream_t stream) {
   p.epi = g->epilogue; p.alpha = g->alpha; p.p = g->dropout_p; p.site = g->site; p.rng = g->rng;
   hipStream_t s = (hipStream_t)stream;
   if (g->dtype_in == GSTVD_BF16 && (g->dtype_out == GSTVD_BF16 || g->dtype_out == GSTVD_F32)) {
-    int rc = gemm_dma_dispatch(p, g->batch, g->a_kmajor, g->b_kmajor, g->dtype_out == GSTVD_F32, s);
+    int rc = gemm_dma256_dispatch(p, g->batch, g->a_kmajor, g->b_kmajor, g->dtype_out == GSTVD_F32, s);
+    if (rc != GSTVD_E_UNSUPPORTED) return rc;
+    rc = gemm_dma_dispatch(p, g->batch, g->a_kmajor, g->b_kmajor, g->dtype_out == GSTVD_F32, s);
     if (rc != GSTVD_E_UNSUPPORTED) return rc;
   }
   if (g->dtype_in == GSTVD_BF16 && g->dtype_out == GSTVD_BF16) return launch_dtype<bf16, bf16>(p, g->batch, g->a_kmajor, g->b_kmajor, s);

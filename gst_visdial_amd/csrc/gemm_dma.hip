@@ -64,27 +64,22 @@ struct DmaUnits {
   }
 };
 
+// One output tile: the whole K loop + epilogue.  `wg` is the tile's index in the problem's L2-friendly order.
 template <typename OT, int BM, int BN, int WM, int WN, bool AKM, bool BKM, int NS>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(GemmP p, int ntn, int nwg) {
+DEVFN void dma_tile(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char* smem) {
   constexpr int NT = WM * WN * 64, WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   constexpr int NPA = A_BYTES / (NT * 16), NPB = B_BYTES / (NT * 16), LPS = NPA + NPB;
   static_assert(NPA >= 1 && NPB >= 1, "tile too small for the thread count");
   static_assert((NS - 2) * LPS <= 63, "vmcnt immediate out of range");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  // XCD-aware, L2-friendly tile order.  Blocks b and b+8 share an XCD (private 4 MiB L2): give each XCD a
-  // contiguous run of ids (bijective remap), and number the tiles in column strips 4 n-tiles wide so that the
-  // ~32 workgroups an XCD runs concurrently form an (8 m) x (4 n) block: 12 operand panels feed 32 tiles.
-  const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  // tiles are numbered in column strips 4 n-tiles wide, so ~32 consecutive ids form an (8 m) x (4 n) block
   const int ntm = nwg / ntn;
   const int strip = wg / (4 * ntm), sw = (ntn - strip * 4) < 4 ? (ntn - strip * 4) : 4;
   const int within = wg - strip * 4 * ntm;
-  const int64_t z = blockIdx.y;
   const int64_t m0 = (int64_t)(within / sw) * BM, n0 = (int64_t)(strip * 4 + within % sw) * BN;
 
   DmaUnits<BM, AKM, NPA, NT> ua;
@@ -140,6 +135,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(GemmP p, int ntn
       gemm_epilogue_tile<bf16, OT>(p, dk, acc[i][j], z, m0 + wm * WTM + i * 16 + li, n0 + wn * WTN + j * 16 + 4 * g);
 }
 
+// XCD-aware block order: blocks b and b+8 share an XCD (private 4 MiB L2); give each XCD a contiguous run of ids
+DEVFN int xcd_remap(int bid, int nwg) {
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+template <typename OT, int BM, int BN, int WM, int WN, bool AKM, bool BKM, int NS>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(GemmP p, int ntn, int nwg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  dma_tile<OT, BM, BN, WM, WN, AKM, BKM, NS>(p, blockIdx.y, xcd_remap(blockIdx.x, nwg), ntn, nwg, smem);
+}
+
 template <typename OT, int BM, int BN, int WM, int WN, bool AKM, bool BKM, int NS>
 static int dma_launch(const GemmP& p, int64_t batch, hipStream_t s) {
   constexpr int lds = NS * (BM + BN) * 128;
@@ -160,11 +167,11 @@ static int dma_layout(const GemmP& p, int64_t batch, hipStream_t s) {
   if (variant == 1) return GSTVD_E_UNSUPPORTED;
   const int64_t big = ((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
   if (p.M >= 256 && p.N >= 128 && big >= 96) {
-    if (variant == 2) return dma_launch<OT, 128, 128, 2, 2, AKM, BKM, 4>(p, batch, s);
-    return dma_launch<OT, 128, 128, 2, 4, AKM, BKM, 4>(p, batch, s);
+    if (variant == 2) return dma_launch<OT, 128, 128, 2, 4, AKM, BKM, 4>(p, batch, s);
+    return dma_launch<OT, 128, 128, 2, 4, AKM, BKM, 5>(p, batch, s);
   }
-  if (variant == 3) return dma_launch<OT, 64, 64, 2, 2, AKM, BKM, 6>(p, batch, s);
-  return dma_launch<OT, 64, 64, 2, 2, AKM, BKM, 4>(p, batch, s);
+  if (variant == 3) return dma_launch<OT, 64, 64, 2, 2, AKM, BKM, 4>(p, batch, s);
+  return dma_launch<OT, 64, 64, 2, 2, AKM, BKM, 8>(p, batch, s);
 }
 
 template <typename OT>

@@ -1,0 +1,261 @@
+// 256x256x32 bf16 MFMA GEMM tile, 8 waves (each 128x64), LDS-DMA 4-stage ring.
+//
+// Measured on MI355X (profiles/r01_pmc_gemm_l2_fetch.json): with 128x128x64 tiles the main loop is bound by the rate
+// at which a CU can fill LDS (~35-50 GB/s per CU, L2 hit 70-82 %), i.e. by bytes staged per FLOP (1 B / 64 FLOP).
+// This tile stages the same 32 KB per K-step but does 4x the MFMA work per step over half the K depth:
+// 1 B / 128 FLOP.  Same ring / counted-vmcnt / one-barrier structure and the same zero-page tails as gemm_dma.hip.
+//
+// LDS images for a 32-deep K step:
+//   row-major operand  : 256 rows x 64 B; 16-byte slot s of row r lives at slot s ^ (2*((r>>3)&1))   (conflict-free
+//                        ds_read_b128 for the 16x16x32 fragment pattern; found by exhaustive search over the b128 lane groups)
+//   k-major operand    : 32 k-rows x 512 B; 32-byte block b of k-row r lives at block b ^ ((r&3) | ((r>>3)&1)<<2)
+#include "gemm_common.h"
+#include <stdlib.h>
+
+static __device__ __attribute__((aligned(256))) char g_zero_page256[256];
+constexpr int NS256 = 5;    // ring depth: 5 x 32 KB = the whole 160 KB LDS of a CU
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+DEVFN int rm32_off(int row, int slot) { return row * 64 + ((slot ^ (((row >> 3) & 1) << 1)) << 4); }
+template <int BX> DEVFN int km32_off(int krow, int col) {
+  constexpr int NB = BX / 16;
+  const int f = (krow & 3) | (((krow >> 3) & 1) << 2);
+  return krow * (BX * 2) + ((((col >> 4) ^ f) & (NB - 1)) << 5) + ((col & 15) << 1);
+}
+
+template <int BX, bool KM> DEVFN bf16x8 frag32(const char* img, int xb, int lane) {
+  const int g = lane >> 4, li = lane & 15;
+  if (!KM) {
+    return *(const bf16x8*)(img + rm32_off(xb + li, g));
+  } else {
+    const int kr = 8 * g + (li >> 2), col = xb + 4 * (lane & 3);
+    s16x4 lo = lds_tr16(img + km32_off<BX>(kr, col));
+    s16x4 hi = lds_tr16(img + km32_off<BX>(kr + 4, col));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  }
+}
+
+template <int BX, bool KM, int NP, int NT>
+struct Dma32 {
+  const char* ptr[NP];
+  int kofs[NP];
+  bool okx[NP];
+  int64_t kstep;
+  DEVFN void init(const char* g, int64_t ld, int64_t x0, int64_t X, int tid) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int u = i * NT + tid;
+      int64_t x;
+      if (!KM) {
+        const int r = u >> 2, ls = (u & 3) ^ (((r >> 3) & 1) << 1);
+        x = x0 + r;
+        kofs[i] = ls * 8;
+        ptr[i] = g + (x * ld + ls * 8) * 2;
+      } else {
+        constexpr int VPR = BX / 8, NB = BX / 16;
+        const int kr = u / VPR, cu = u % VPR;
+        const int f = (kr & 3) | (((kr >> 3) & 1) << 2);
+        const int lb = ((cu >> 1) ^ f) & (NB - 1);
+        x = x0 + lb * 16 + (cu & 1) * 8;
+        kofs[i] = kr;
+        ptr[i] = g + ((int64_t)kr * ld + x) * 2;
+      }
+      okx[i] = x < X;
+    }
+    kstep = KM ? 32 * ld * 2 : 64;
+  }
+  DEVFN void issue(int64_t kt, int64_t K, char* img, int wave) const {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const bool ok = okx[i] && (kt * 32 + kofs[i] < K);
+      const char* src = ok ? ptr[i] + kt * kstep : (const char*)g_zero_page256;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(img + (i * NT + wave * 64) * 16), 16, 0, 0);
+    }
+  }
+  // Pull the K-slice `kt` into this XCD's L2 ahead of time: a 4-byte LDS-DMA per unit into a per-wave scratch
+  // (no VGPR destination, so nothing to protect; it only occupies a vmcnt slot, the count per stage stays constant).
+  DEVFN void prefetch(int64_t kt, int64_t K, char* scratch, int wave) const {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const bool ok = okx[i] && (kt * 32 + kofs[i] < K);
+      const char* src = ok ? ptr[i] + kt * kstep : (const char*)g_zero_page256;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(scratch + wave * 256), 4, 0, 0);
+    }
+  }
+};
+
+template <typename OT, bool AKM, bool BKM, int PF>
+DEVFN void dma_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char* smem) {
+  constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NS = NS256, NT = 512;
+  constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;     // 8 x 4 accumulator tiles per wave
+  constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;
+  constexpr int NPA = A_BYTES / (NT * 16), NPB = B_BYTES / (NT * 16), LPS = (NPA + NPB) * (PF > 0 ? 2 : 1);
+  char* scratch = smem;   // (prefetch experiment only; unused when PF == 0)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  // column strips 2 n-tiles wide: ~32 concurrent tiles of an XCD form a (16 m) x (2 n) block
+  const int ntm = nwg / ntn;
+  const int strip = wg / (2 * ntm), sw = (ntn - strip * 2) < 2 ? (ntn - strip * 2) : 2;
+  const int within = wg - strip * 2 * ntm;
+  const int64_t m0 = (int64_t)(within / sw) * BM, n0 = (int64_t)(strip * 2 + within % sw) * BN;
+
+  Dma32<BM, AKM, NPA, NT> ua;
+  Dma32<BN, BKM, NPB, NT> ub;
+  ua.init(p.A + z * p.sA * 2, p.lda, m0, p.M, tid);
+  ub.init(p.B + z * p.sB * 2, p.ldb, n0, p.N, tid);
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int64_t nkt = (p.K + 31) / 32;
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) {
+    ua.issue(s, p.K, smem + s * STAGE, wave);
+    ub.issue(s, p.K, smem + s * STAGE + A_BYTES, wave);
+    if (PF > 0) { ua.prefetch(s + PF, p.K, scratch, wave); ub.prefetch(s + PF, p.K, scratch, wave); }
+  }
+  int slot = 0, fill = NS - 1;
+  for (int64_t t = 0; t < nkt; ++t) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPS) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // PF < 0 are timing-only ablations (wrong results): -1 = no DMA inside the loop, -2 = no LDS reads / MFMA
+    if (PF != -1) {
+      ua.issue(t + NS - 1, p.K, smem + fill * STAGE, wave);
+      ub.issue(t + NS - 1, p.K, smem + fill * STAGE + A_BYTES, wave);
+    } else {
+      ua.issue(1 << 20, p.K, smem + fill * STAGE, wave);      // zero-page DMAs keep the vmcnt bookkeeping identical
+      ub.issue(1 << 20, p.K, smem + fill * STAGE + A_BYTES, wave);
+    }
+    if (PF > 0) { ua.prefetch(t + NS - 1 + PF, p.K, scratch, wave); ub.prefetch(t + NS - 1 + PF, p.K, scratch, wave); }
+    const char* cA = smem + slot * STAGE;
+    const char* cB = cA + A_BYTES;
+    if (PF != -2) {
+      bf16x8 fb[NI];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) fb[j] = frag32<BN, BKM>(cB, wn * WTN + j * 16, lane);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const bf16x8 fa = frag32<BM, AKM>(cA, wm * WTM + i * 16, lane);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = mfma_bf16_k32(fb[j], fa, acc[i][j]);
+      }
+    }
+    slot = (slot + 1 == NS) ? 0 : slot + 1;
+    fill = (fill + 1 == NS) ? 0 : fill + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  const int g = lane >> 4, li = lane & 15;
+  const DropKey dk = make_drop((p.epi & GSTVD_EPI_DROPOUT) ? p.p : 0.f, p.site, p.rng);
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+      gemm_epilogue_tile<bf16, OT>(p, dk, acc[i][j], z, m0 + wm * WTM + i * 16 + li, n0 + wn * WTN + j * 16 + 4 * g);
+}
+
+DEVFN int xcd_remap256(int bid, int nwg) {
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+template <typename OT, bool AKM, bool BKM, int PF>
+__global__ __launch_bounds__(512) void gemm_dma256_kernel(GemmP p, int ntn, int nwg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  dma_tile256<OT, AKM, BKM, PF>(p, blockIdx.y, xcd_remap256(blockIdx.x, nwg), ntn, nwg, smem);
+}
+
+template <typename OT, bool AKM, bool BKM, int PF>
+__global__ __launch_bounds__(512) void gemm_dma256_grouped_kernel(const gstvd_gemm_t* tab, const int* tile_off, int nprob, int total) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int gid = xcd_remap256(blockIdx.x, total);
+  int lo = 0, hi = nprob - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tile_off[mid] <= gid) lo = mid; else hi = mid - 1; }
+  const gstvd_gemm_t& g = tab[lo];
+  GemmP p;
+  p.A = (const char*)g.A; p.B = (const char*)g.B; p.C = (char*)g.C;
+  p.bias = g.bias; p.addend = (const char*)g.addend; p.aux = (char*)g.aux;
+  p.M = g.M; p.N = g.N; p.K = g.K;
+  p.lda = g.lda; p.ldb = g.ldb; p.ldc = g.ldc; p.ldadd = g.ldadd; p.ldaux = g.ldaux;
+  p.sA = p.sB = p.sC = p.sAdd = p.sAux = 0;
+  p.epi = g.epilogue; p.alpha = g.alpha; p.p = g.dropout_p; p.site = g.site; p.rng = g.rng;
+  const int ntn = (int)((g.N + 255) / 256), ntm = (int)((g.M + 255) / 256);
+  dma_tile256<OT, AKM, BKM, PF>(p, 0, gid - tile_off[lo], ntn, ntm * ntn, smem);
+}
+
+constexpr int LDS256 = NS256 * (256 + 256) * 64 + (NS256 < 5 ? 8 * 256 : 0);     // ring + per-wave prefetch scratch
+constexpr int PFD = 10;                                     // prefetch distance in 32-deep K steps
+static int pf_enabled() { static const int v = [] { const char* e = getenv("GSTVD_GEMM_PF"); return e ? atoi(e) : 0; }(); return v; }
+
+template <typename OT, bool AKM, bool BKM>
+static int launch256(const GemmP& p, int64_t batch, hipStream_t s) {
+  auto k0 = gemm_dma256_kernel<OT, AKM, BKM, 0>;
+  auto ka = gemm_dma256_kernel<OT, AKM, BKM, -1>;
+  auto kb = gemm_dma256_kernel<OT, AKM, BKM, -2>;
+  static int attr_rc = ensure_lds(k0, LDS256) | ensure_lds(ka, LDS256) | ensure_lds(kb, LDS256);
+  if (attr_rc) return attr_rc;
+  static const int abl = [] { const char* e = getenv("GSTVD_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
+  const int ntm = (int)((p.M + 255) / 256), ntn = (int)((p.N + 255) / 256);
+  hipLaunchKernelGGL(abl == 1 ? ka : (abl == 2 ? kb : k0), dim3((unsigned)(ntm * ntn), (unsigned)batch), dim3(512), LDS256, s, p, ntn, ntm * ntn);
+  GSTVD_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename OT>
+static int launch256_layout(const GemmP& p, int64_t batch, int akm, int bkm, hipStream_t s) {
+  if (!akm && !bkm) return launch256<OT, false, false>(p, batch, s);
+  if (!akm && bkm) return launch256<OT, false, true>(p, batch, s);
+  if (akm && bkm) return launch256<OT, true, true>(p, batch, s);
+  return GSTVD_E_UNSUPPORTED;
+}
+
+// Single-problem policy: the big tile only pays when its (4x smaller) grid still covers most of the chip.
+int gemm_dma256_dispatch(const GemmP& p, int64_t batch, int akm, int bkm, int out_f32, hipStream_t s) {
+  static const int variant = [] { const char* e = getenv("GSTVD_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
+  static const int min_tiles = [] { const char* e = getenv("GSTVD_GEMM256_MIN_TILES"); return e ? atoi(e) : 120; }();
+  if (variant == 1 || variant == 2 || variant == 4) return GSTVD_E_UNSUPPORTED;
+  const int64_t tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256) * batch;
+  if (p.M < 256 || p.N < 256 || tiles < min_tiles) return GSTVD_E_UNSUPPORTED;
+  return out_f32 ? launch256_layout<float>(p, batch, akm, bkm, s) : launch256_layout<bf16>(p, batch, akm, bkm, s);
+}
+
+template <typename OT, bool AKM, bool BKM>
+static int grouped256(const gstvd_gemm_t* tab, const int* off, int nprob, int total, hipStream_t s) {
+  auto k0 = gemm_dma256_grouped_kernel<OT, AKM, BKM, 0>;
+  static int attr_rc = ensure_lds(k0, LDS256);
+  if (attr_rc) return attr_rc;
+  hipLaunchKernelGGL(k0, dim3((unsigned)total), dim3(512), LDS256, s, tab, off, nprob, total);
+  GSTVD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gstvd_gemm_group_tile(void) { return 256; }
+
+extern "C" int gstvd_gemm_grouped(const gstvd_gemm_t* table_dev, const int32_t* tile_off_dev, int64_t nprob, int64_t total_tiles,
+                                  int32_t dtype_in, int32_t dtype_out, int32_t a_kmajor, int32_t b_kmajor, gstvd_stream_t stream) {
+  if (!table_dev || !tile_off_dev) return GSTVD_E_NULL;
+  if (nprob <= 0 || total_tiles <= 0) return GSTVD_E_SHAPE;
+  if (dtype_in != GSTVD_BF16) return GSTVD_E_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const int n = (int)nprob, t = (int)total_tiles;
+  if (dtype_out == GSTVD_F32) {
+    if (a_kmajor && b_kmajor) return grouped256<float, true, true>(table_dev, tile_off_dev, n, t, s);
+    if (!a_kmajor && b_kmajor) return grouped256<float, false, true>(table_dev, tile_off_dev, n, t, s);
+    if (!a_kmajor && !b_kmajor) return grouped256<float, false, false>(table_dev, tile_off_dev, n, t, s);
+  } else if (dtype_out == GSTVD_BF16) {
+    if (a_kmajor && b_kmajor) return grouped256<bf16, true, true>(table_dev, tile_off_dev, n, t, s);
+    if (!a_kmajor && b_kmajor) return grouped256<bf16, false, true>(table_dev, tile_off_dev, n, t, s);
+    if (!a_kmajor && !b_kmajor) return grouped256<bf16, false, false>(table_dev, tile_off_dev, n, t, s);
+  }
+  return GSTVD_E_UNSUPPORTED;
+}

@@ -287,6 +287,7 @@ class Engine(object):
             self.rng = ops.Rng(device, seed=int(self.model.params.get("amd_seed", 0)))
             self.anchor = torch.zeros(1, device=device, requires_grad=True)
             self.colsums = ops.ColsumBatch(device)
+            self.wgrads = ops.GemmGroup(device, a_km=True, b_km=True)
         self.flat.refresh_shadow()
 
     def _bind_views(self):
@@ -329,7 +330,8 @@ class Engine(object):
             self.tape.append(lambda: self._hook(off))
 
     def _hook(self, off):
-        self.colsums.flush()          # bias / LayerNorm gradients of the finished region must be final first
+        self.wgrads.flush()           # weight / bias / LayerNorm gradients of the finished region must be final first
+        self.colsums.flush()
         self.grad_hook(off)
 
     # ------------------------------------------------------------------------------------------ ops
@@ -347,7 +349,7 @@ class Engine(object):
     def _lin_bwd(self, x, y, w, b, N, K, need_dx):
         dy, M = y.g, x.M      # for a GELU output y.g already holds d(pre-activation): its producer applied gelu'
         gw, acc = self.grad_slot(w)
-        ops.gemm(dy, x.t, gw, N, K, M, a_km=True, b_km=True, addend=gw if acc else None)
+        self.wgrads.add(dy, x.t, gw, N, K, M, acc)       # deferred: all weight-gradient GEMMs run as one grouped launch
         if not y.bias_done:
             gb, accb = self.grad_slot(b)
             nslab = (M + 63) // 64
@@ -666,12 +668,14 @@ class Engine(object):
                     gv.copy_(p.grad)
         self.written = set()
         self.colsums.reset()
+        self.wgrads.reset()
         logits = st["logits"]
         logits.g = self.buf(st["Md"], flat.Vp)
         gs = gloss.reshape(1).float().contiguous() if gloss is not None else None
         ops.ce_bwd(logits.t, st["lab"], st["lse"], st["stats"], gs, True, st["Md"], st["V"], logits.g, ignore_index=st["pad"])
         for fn in reversed(st["tape"]):
             fn()
+        self.wgrads.flush()
         self.colsums.flush()
         if self.grad_hook is not None:
             self.grad_hook(0)

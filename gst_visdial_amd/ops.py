@@ -30,6 +30,9 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+GEMM256_MIN_TILES = int(__import__("os").environ.get("GSTVD_GEMM256_MIN_TILES", "120"))
+
+
 class Profiler(object):
     """Optional per-launch timing with HIP events on the launch stream (bench.py's kernel breakdown).
     Off by default; `with ops.Profiler() as p:` records (tag, flops, bytes, start, end) per wrapped call."""
@@ -79,6 +82,8 @@ def gemm_tag(dtype_in, a_km, b_km, M, N, batch):
     """Name of the kernel instantiation gstvd_gemm dispatches to (same rule as launch_layout in csrc/gemm.hip)."""
     big = ((M + 127) // 128) * ((N + 127) // 128) * batch
     tile = 128 if (M >= 256 and N >= 128 and big >= 96) else 64
+    if dtype_in == BF16 and M >= 256 and N >= 256 and ((M + 255) // 256) * ((N + 255) // 256) * batch >= GEMM256_MIN_TILES:
+        tile = 256
     lay = {(0, 0): "nt", (0, 1): "nn", (1, 1): "tn", (1, 0): "tt"}[(int(a_km), int(b_km))]
     return "gemm_%s_%s_%d" % ("bf16" if dtype_in == BF16 else "f32", lay, tile)
 
@@ -129,6 +134,71 @@ def gemm(A, B, C_out, M, N, K, *, a_km=False, b_km=False, bias=None, addend=None
     _prof_end(e0, gemm_tag(d.dtype_in, a_km, b_km, M, N, batch), 2.0 * M * N * K * batch,
               float(batch) * ((M * K + N * K) * A.element_size() + M * N * C_out.element_size()), (M, N, K, batch))
     return C_out
+
+
+class GemmGroup(object):
+    """Deferred GEMMs that share dtypes / operand layouts, executed as ONE grouped launch (gstvd_gemm_grouped).
+    The engine queues every weight-gradient GEMM of a backward pass here.  Device tables are cached by content
+    (arena addresses are static from step to step), so steady state is a single launch with no host->device copy."""
+
+    def __init__(self, device, a_km=True, b_km=True):
+        self.device, self.a_km, self.b_km = device, a_km, b_km
+        self.items, self.cache, self.keep = [], {}, []
+        self.dtype_in = self.dtype_out = None
+
+    def add(self, A, B, C_out, M, N, K, accumulate):
+        di, do = dt(A), dt(C_out)
+        if self.items and (di, do) != (self.dtype_in, self.dtype_out):
+            self.flush()
+        self.dtype_in, self.dtype_out = di, do
+        self.keep.append((A, B, C_out))      # keep the operands alive until the launch
+        self.items.append((_p(A), _p(B), _p(C_out), M, N, K, A.stride(-2), B.stride(-2), C_out.stride(-2), int(bool(accumulate))))
+
+    def reset(self):
+        self.items, self.keep = [], []
+
+    def flush(self):
+        if not self.items:
+            return
+        keep, self.keep = self.keep, []      # released when this call returns (after the launch is enqueued)
+        if self.dtype_in != BF16:            # fp32 parity mode: plain launches
+            lib = L.load()
+            for (a, b, c, M, N, K, lda, ldb, ldc, acc) in self.items:
+                d = L.GemmDesc()
+                d.A, d.B, d.C, d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.batch = a, b, c, M, N, K, lda, ldb, ldc, 1
+                d.dtype_in, d.dtype_out, d.a_kmajor, d.b_kmajor, d.alpha = self.dtype_in, self.dtype_out, int(self.a_km), int(self.b_km), 1.0
+                if acc:
+                    d.addend, d.ldadd, d.epilogue = c, ldc, EPI_ADD
+                L.check("gstvd_gemm", lib.gstvd_gemm(C.byref(d), _stream()))
+            self.items = []
+            return
+        key = tuple(self.items)
+        hit = self.cache.get(key)
+        if hit is None:
+            arr = (L.GemmDesc * len(key))()
+            offs, tiles, flops = [], 0, 0.0
+            T = int(L.load().gstvd_gemm_group_tile())
+            for d, (a, b, c, M, N, K, lda, ldb, ldc, acc) in zip(arr, key):
+                d.A, d.B, d.C, d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.batch = a, b, c, M, N, K, lda, ldb, ldc, 1
+                d.dtype_in, d.dtype_out, d.a_kmajor, d.b_kmajor, d.alpha = self.dtype_in, self.dtype_out, int(self.a_km), int(self.b_km), 1.0
+                if acc:
+                    d.addend, d.ldadd, d.epilogue = c, ldc, EPI_ADD
+                offs.append(tiles)
+                tiles += ((M + T - 1) // T) * ((N + T - 1) // T)
+                flops += 2.0 * M * N * K
+            tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+            off = torch.tensor(offs, dtype=torch.int32).to(self.device)
+            hit = (tab, off, len(key), tiles, flops)
+            if len(self.cache) > 64:
+                self.cache.clear()
+            self.cache[key] = hit
+        tab, off, n, tiles, flops = hit
+        lib = L.load()
+        e0 = _prof_begin()
+        L.check("gstvd_gemm_grouped", lib.gstvd_gemm_grouped(tab.data_ptr(), off.data_ptr(), n, tiles, self.dtype_in, self.dtype_out,
+                                                             int(self.a_km), int(self.b_km), _stream()))
+        _prof_end(e0, "gemm_grouped_%s" % ("tn" if self.a_km else "nt"), flops, 0.0, (n, tiles))
+        self.items = []
 
 
 def _ln_desc(mode, dtype, M, H, gamma, beta, mean, rstd, eps, x=None, res=None, y=None, p_pre=0.0, p_post=0.0,
@@ -205,19 +275,20 @@ class ColsumBatch(object):
     def __init__(self, device):
         self.device = device
         self.entries = []            # (partial_ptr, (out0,out1,out2 ptrs), nblk, stride, H, nvec, (acc0,acc1,acc2))
-        self.targets = set()
+        self.targets, self.keep = set(), []
         self.cache = {}
 
     def add(self, partial, outs, nblk, stride, H, nvec, accs):
         ptrs = [o.data_ptr() for o in outs if o is not None]
         if any(p in self.targets for p in ptrs):      # same output twice (shared embedding LayerNorm): keep launch order
             self.flush()
+        self.keep.append((partial, outs))
         self.targets.update(ptrs)
         self.entries.append((partial.data_ptr(), tuple(o.data_ptr() if o is not None else 0 for o in outs), nblk, stride, H,
                              nvec, tuple(int(bool(a)) for a in accs)))
 
     def reset(self):
-        self.entries, self.targets = [], set()
+        self.entries, self.targets, self.keep = [], set(), []
 
     def flush(self):
         if not self.entries:
@@ -244,7 +315,7 @@ class ColsumBatch(object):
         e0 = _prof_begin()
         L.check("gstvd_colsum_batched", lib.gstvd_colsum_batched(tab.data_ptr(), n, blocks, _stream()))
         _prof_end(e0, "colsum_batched", 0.0, 0.0)
-        self.entries, self.targets = [], set()
+        self.entries, self.targets, self.keep = [], set(), []
 
 
 def locgrad(dh, loc, M, H, dw_loc, accumulate):

@@ -67,6 +67,15 @@ typedef struct {
 } gstvd_gemm_t;
 int gstvd_gemm(const gstvd_gemm_t* g, gstvd_stream_t s);
 
+/* Grouped form: `table_dev` is a DEVICE array of nprob independent problems (batch ignored, = 1) that share dtypes
+ * and operand layouts; they run as ONE launch over all their 128x128 tiles.  tile_off_dev[i] = first tile id of
+ * problem i (ceil(M/128)*ceil(N/128) tiles each), device int32[nprob].  The engine uses it for the deferred
+ * weight-gradient GEMMs of a whole backward pass (dW = dy^T x: a_kmajor = b_kmajor = 1, fp32 out, EPI_ADD to
+ * accumulate), whose individual grids are too small to fill the chip.  bf16 inputs only. */
+int gstvd_gemm_group_tile(void);
+int gstvd_gemm_grouped(const gstvd_gemm_t* table_dev, const int32_t* tile_off_dev, int64_t nprob, int64_t total_tiles,
+                       int32_t dtype_in, int32_t dtype_out, int32_t a_kmajor, int32_t b_kmajor, gstvd_stream_t s);
+
 /* ---- fused (bias-free) dropout + residual + LayerNorm, and the two embedding front ends -----
  * mode GSTVD_LN_RESID : h = drop_pre(x) + res ; y = drop_post(LN(h))   (BertSelfOutput/BertOutput/
  *        BertBiOutput, vilbert_dialog.py:416-420,458-462,735-742; HF BertSelfOutput/BertOutput)

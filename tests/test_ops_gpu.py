@@ -37,7 +37,8 @@ def rnd(*shape, dtype=torch.float32, seed=0, s=1.0):
 
 # ------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K", [(200, 96, 64), (300, 256, 128), (111, 64, 320), (592, 1024, 256), (1024, 768, 192)])
+@pytest.mark.parametrize("M,N,K", [(200, 96, 64), (300, 256, 128), (111, 64, 320), (592, 1024, 256), (1024, 768, 192),
+                                   (2816, 3072, 160), (3000, 2824, 104)])      # the last two take the 256x256x32 tile
 def test_gemm_forward_bias(dtype, M, N, K):
     o = ops()
     x, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, s=0.1)
@@ -60,7 +61,7 @@ def test_gemm_asymmetric_identity(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K", [(200, 64, 96), (300, 128, 256), (592, 256, 1024)])
+@pytest.mark.parametrize("M,N,K", [(200, 64, 96), (300, 128, 256), (592, 256, 1024), (3000, 2824, 200)])
 def test_gemm_dgrad_kmajor_b(dtype, M, N, K):
     """dx[M,N] = dy[M,K] @ W[K,N]  with W stored [K,N] (k-major B)."""
     o = ops()
@@ -72,7 +73,7 @@ def test_gemm_dgrad_kmajor_b(dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("rows,N,K", [(111, 64, 96), (300, 128, 256), (4100, 256, 128)])
+@pytest.mark.parametrize("rows,N,K", [(111, 64, 96), (300, 128, 256), (4100, 256, 128), (333, 3072, 2568)])
 def test_gemm_wgrad_accumulate(dtype, rows, N, K):
     """dW[N,K] (+)= dy[rows,N]^T @ x[rows,K]; fp32 output, both operands k-major, contraction not a tile multiple."""
     o = ops()
@@ -382,3 +383,19 @@ def test_cast_roundtrip_and_adamw():
     check("adamw_m", m, mr, torch.float32)
     check("adamw_v", v, vr, torch.float32)
     assert torch.equal(shadow, p.to(torch.bfloat16))
+
+
+def test_gemm_grouped_matches_individual_launches():
+    """The deferred weight-gradient path: several dW = dy^T x problems (different shapes, one accumulating) in one launch."""
+    o = ops()
+    grp = o.GemmGroup(DEV, a_km=True, b_km=True)
+    refs = []
+    for i, (rows, N, K, acc) in enumerate([(333, 128, 256, False), (592, 1024, 256, True), (100, 64, 96, False), (4096, 768, 768, False)]):
+        dy, x = rnd(rows, N, dtype=torch.bfloat16, seed=90 + i), rnd(rows, K, dtype=torch.bfloat16, seed=95 + i)
+        dw = rnd(N, K, seed=99 + i)
+        ref = dy.float().t() @ x.float() + (dw if acc else 0)
+        grp.add(dy, x, dw, N, K, rows, acc)
+        refs.append((dw, ref))
+    grp.flush()
+    for i, (dw, ref) in enumerate(refs):
+        check("gemm_grouped_%d" % i, dw, ref, torch.bfloat16, 2.0)
