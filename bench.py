@@ -67,7 +67,7 @@ def synthetic_rows(B, T, R, U, F, V, seed, device):
     return {k: v.to(device) for k, v in d.items()}
 
 
-def build_model(device, precision, seed):
+def build_model(device, precision, seed, streams=True):
     from gst_visdial_amd.config import bert_base_enc_config, bert_base_dec_config
     from gst_visdial_amd.modules import VisualDialogEncoder, VisualDialogDecoder, EncoderDecoderModel
     d = tempfile.mkdtemp(prefix="gstvd_bench_")
@@ -76,7 +76,8 @@ def build_model(device, precision, seed):
     with open(os.path.join(d, "dec.json"), "w") as f:
         json.dump(bert_base_dec_config(), f)
     params = dict(model_enc_config=os.path.join(d, "enc.json"), model_dec_config=os.path.join(d, "dec.json"), gpu_ids=[0],
-                  model="enc_dec_a", mode="vd_train", batch_size=16, device=device, amd_precision=precision, amd_seed=seed)
+                  model="enc_dec_a", mode="vd_train", batch_size=16, device=device, amd_precision=precision, amd_seed=seed,
+                  amd_streams=streams)
     torch.manual_seed(seed)
     enc, dec = VisualDialogEncoder(params), VisualDialogDecoder(params)
     model = EncoderDecoderModel(params, enc, dec)
@@ -125,6 +126,9 @@ def main():
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--grad-compress", default=None, choices=[None, "bf16"])
     ap.add_argument("--breakdown-json", default=None, help="write the per-kernel breakdown here")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay the whole train step as one hipGraph (auto: on for 1 GPU, off for N>1)")
+    ap.add_argument("--no-streams", action="store_true", help="run the vision stream on the main HIP stream")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -145,7 +149,7 @@ def main():
     from gst_visdial_amd.dp import GradSync
 
     B, T, R, U, F = args.rows_per_gpu, args.seq_len, 37, 25, 2048
-    model, params = build_model(device, args.precision, seed=1234)      # same init on every rank
+    model, params = build_model(device, args.precision, seed=1234, streams=not args.no_streams)      # same init on every rank
     V = model.decoder.config.vocab_size
     model.train()
     batch = synthetic_rows(B, T, R, U, F, V, 1234 + rank, device)
@@ -169,8 +173,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    eager_step = step
+    use_graph = args.graph == "on" or (args.graph == "auto" and world == 1)
+    for _ in range(max(args.warmup, 2) if use_graph else args.warmup):
         loss = step()
+    if use_graph:
+        # The step is ~1000 kernel launches; issued from Python they cost ~18 ms of host time.  Capture one full step
+        # (forward, backward on both HIP streams, fused AdamW) and replay it: same kernels, same work, no host in the loop.
+        # Device-resident state (dropout offset, AdamW step counter) advances inside the graph.
+        from gst_visdial_amd.graph import GraphedStep
+        step = GraphedStep(eager_step, warmup=0)
+        for _ in range(args.warmup):
+            loss = step()
     barrier()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -189,10 +203,17 @@ def main():
     ms_step = dt * 1000.0 / args.steps
     rows_s = B * world * args.steps / dt
 
+    # host issue time of one step (no sync inside): if this approaches ms_per_step the run is launch bound
+    torch.cuda.synchronize()
+    th = time.perf_counter()
+    eager_step()
+    host_ms = (time.perf_counter() - th) * 1e3
+    torch.cuda.synchronize()
+
     roofline, breakdown = None, None
     if rank == 0 and not args.no_breakdown:
         with ops.Profiler() as prof:
-            step()
+            eager_step()
         agg = prof.summary()
         gemms = {k: v for k, v in agg.items() if k.startswith("gemm_")}
         dom = max(gemms, key=lambda k: gemms[k]["ms"])
@@ -232,7 +253,8 @@ def main():
                "config": {"workload": "enc_dec_a train step (fwd+loss+bwd+allreduce+AdamW, dropout on), %d rows/GPU, "
                                       "seq_len %d, 37x2048 region features, answer len 25" % (B, T),
                           "global_batch": B * world, "seq_len": T, "parallelism": "dp%d" % world,
-                          "gpu_ms_per_step_events": round(e0.elapsed_time(e1) / args.steps, 3), "final_loss": round(final_loss, 4)},
+                          "gpu_ms_per_step_events": round(e0.elapsed_time(e1) / args.steps, 3), "eager_host_issue_ms_per_step": round(host_ms, 3), "hip_graph": bool(use_graph),
+                          "final_loss": round(final_loss, 4)},
                "roofline": roofline, "cpu_baseline": cpu}
         if breakdown is not None:
             out["kernel_breakdown_ms"] = {k: v["ms"] for k, v in list(breakdown.items())[:12]}

@@ -105,9 +105,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnP p) {
   const int H = (int)f.H;
   const DropKey dpre = make_drop(MODE == GSTVD_LN_RESID ? f.p_pre : 0.f, f.site_pre, f.rng);
   const DropKey dpost = make_drop(f.p_post, f.site_post, f.rng);
-  f32x4 ag[NV], ab[NV], ax[NV];
+  constexpr int NVP = (MODE == GSTVD_LN_EMBED) ? 4 : 3;      // partial vectors per block
+  f32x4 ag[NV], ab[NV], ax[NV], a4[NV];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) ag[i] = ab[i] = ax[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < NV; ++i) ag[i] = ab[i] = ax[i] = a4[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int64_t row0 = (int64_t)blockIdx.x * LN_BWD_RPB + wave * 2;
   f32x4 xh[2][NV], gy[2][NV], dyv[2][NV];
@@ -164,18 +165,29 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnP p) {
           st4((T*)p.dres + row * p.lddres + c, dh);
           ax[i] += dh;
         } else {
-          float* tg = (seg[j] < f.type_vocab) ? p.dtt + seg[j] * f.H : p.dtt_ext + (seg[j] - f.type_vocab) * f.H;
+          // token-type rows 0 / 1 receive a contribution from (almost) every token: reduce them through the block
+          // partials instead of ~M*H atomics onto two rows; rarer segment ids keep the atomic path
+          if (seg[j] == 0) ax[i] += dh;
+          else if (seg[j] == 1 && f.type_vocab > 1) a4[i] += dh;
+          else {
+            float* tg = (seg[j] < f.type_vocab) ? p.dtt + seg[j] * f.H : p.dtt_ext + (seg[j] - f.type_vocab) * f.H;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            atomicAdd(p.dword + id[j] * f.H + c + e, dh[e]);
-            atomicAdd(p.dpos + tpos[j] * f.H + c + e, dh[e]);
-            atomicAdd(tg + c + e, dh[e]);
+            for (int e = 0; e < 4; ++e) atomicAdd(tg + c + e, dh[e]);
+          }
+          // padded positions have an exactly-zero gradient (their keys are masked everywhere): skip their atomics,
+          // which would all hit the [PAD] word row
+          if (dh[0] != 0.f || dh[1] != 0.f || dh[2] != 0.f || dh[3] != 0.f) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              atomicAdd(p.dword + id[j] * f.H + c + e, dh[e]);
+              atomicAdd(p.dpos + tpos[j] * f.H + c + e, dh[e]);
+            }
           }
         }
       }
     }
   }
-  float* mine = red + (int64_t)wave * 3 * H;
+  float* mine = red + (int64_t)wave * NVP * H;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = lane * 4 + i * 256;
@@ -183,13 +195,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnP p) {
       *(f32x4*)(mine + c) = ag[i];
       *(f32x4*)(mine + H + c) = ab[i];
       *(f32x4*)(mine + 2 * H + c) = ax[i];
+      if (NVP == 4) *(f32x4*)(mine + 3 * H + c) = a4[i];
     }
   }
   __syncthreads();
-  float* out = p.partial + (int64_t)blockIdx.x * 3 * H;
-  for (int i = threadIdx.x * 4; i < 3 * H; i += 1024) {
-    f32x4 a = *(const f32x4*)(red + i) + *(const f32x4*)(red + 3 * H + i) + *(const f32x4*)(red + 6 * H + i) +
-              *(const f32x4*)(red + 9 * H + i);
+  float* out = p.partial + (int64_t)blockIdx.x * NVP * H;
+  for (int i = threadIdx.x * 4; i < NVP * H; i += 1024) {
+    f32x4 a = *(const f32x4*)(red + i) + *(const f32x4*)(red + NVP * H + i) + *(const f32x4*)(red + 2 * NVP * H + i) +
+              *(const f32x4*)(red + 3 * NVP * H + i);
     *(f32x4*)(out + i) = a;
   }
 }
@@ -338,9 +351,9 @@ extern "C" int64_t gstvd_ln_bwd_blocks(int64_t M) { return (M + LN_BWD_RPB - 1) 
 template <typename T, int MODE>
 static int ln_bwd_nv(const LnP& p, hipStream_t s) {
   dim3 grid((unsigned)gstvd_ln_bwd_blocks(p.f.M)), block(256);
-  size_t lds = (size_t)4 * 3 * p.f.H * sizeof(float);
+  size_t lds = (size_t)4 * (MODE == GSTVD_LN_EMBED ? 4 : 3) * p.f.H * sizeof(float);
   if (lds > 48 * 1024) {
-    static int rc8 = (int)hipFuncSetAttribute((const void*)ln_bwd_kernel<T, MODE, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 3 * 2048 * 4);
+    static int rc8 = (int)hipFuncSetAttribute((const void*)ln_bwd_kernel<T, MODE, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4 * 2048 * 4);
     if (rc8) return rc8;
   }
   if (p.f.H <= 256) hipLaunchKernelGGL((ln_bwd_kernel<T, MODE, 1>), grid, block, lds, s, p);

@@ -267,6 +267,8 @@ class Engine(object):
         self.accumulate, self.written = False, set()
         self.stats = {}
         self._validate = True
+        self.use_streams = bool(model.params.get("amd_streams", True))
+        self.tag = "t"
 
     # ------------------------------------------------------------------------------------------ setup
     def prepare(self, device):
@@ -286,6 +288,7 @@ class Engine(object):
             self.arena = Arena(device)
             self.rng = ops.Rng(device, seed=int(self.model.params.get("amd_seed", 0)))
             self.anchor = torch.zeros(1, device=device, requires_grad=True)
+            self.side = torch.cuda.Stream(device=device)
             self.colsums = ops.ColsumBatch(device)
             self.wgrads = ops.GemmGroup(device, a_km=True, b_km=True)
         self.flat.refresh_shadow()
@@ -322,17 +325,56 @@ class Engine(object):
 
     def push(self, fn):
         if self.rec:
-            self.tape.append(fn)
+            self.tape.append((self.tag, fn))
 
     def mark(self, key):
         if self.rec and self.grad_hook is not None:
             off = self.flat.marks[key]
-            self.tape.append(lambda: self._hook(off))
+            self.tape.append(("t", lambda: self._hook(off)))
 
     def _hook(self, off):
+        if self.use_streams:
+            self._wait("t", "v")
         self.wgrads.flush()           # weight / bias / LayerNorm gradients of the finished region must be final first
         self.colsums.flush()
         self.grad_hook(off)
+
+    # -- two HIP streams: the vision stream's skinny (M = B*37) kernels run beside the text stream's --------------
+    class _On(object):
+        def __init__(self, eng, tag):
+            self.eng, self.tag, self.ctx = eng, tag, None
+
+        def __enter__(self):
+            self.prev = self.eng.tag
+            self.eng.tag = self.tag
+            if self.eng.use_streams and self.tag == "v":
+                self.ctx = torch.cuda.stream(self.eng.side)
+                self.ctx.__enter__()
+
+        def __exit__(self, *a):
+            if self.ctx is not None:
+                self.ctx.__exit__(*a)
+            self.eng.tag = self.prev
+
+    def on(self, tag):
+        return Engine._On(self, tag)
+
+    def _stream_of(self, tag):
+        return self.side if tag == "v" else self.main
+
+    def _wait(self, waiter, waitee):
+        """Stream `waiter` waits for everything queued so far on stream `waitee`."""
+        ev = torch.cuda.Event()
+        ev.record(self._stream_of(waitee))
+        self._stream_of(waiter).wait_event(ev)
+
+    def sync(self, waiter, waitee):
+        """Forward dependency (ops on `waiter` after this point read results of `waitee`); backward mirrors it."""
+        if not self.use_streams:
+            return
+        self._wait(waiter, waitee)
+        if self.rec:
+            self.tape.append(("sync", (waitee, waiter)))
 
     # ------------------------------------------------------------------------------------------ ops
     def lin(self, x, w, b, N, K, gelu=False, need_dx=True):
@@ -417,9 +459,14 @@ class Engine(object):
                 gv.zero_()
             tabs.append(gv)
         nblk = ops.ln_bwd_blocks(M)
-        partial = self.arena.alloc(nblk * 3 * H, torch.float32)
+        partial = self.arena.alloc(nblk * 4 * H, torch.float32)
         ops.ln_bwd(kw, y.g, partial, dword=tabs[0], dpos=tabs[1], dtt=tabs[2], dtt_ext=tabs[3])
-        self._colsums(partial, nblk, H, [prefix + ".ln.w", prefix + ".ln.b", None])
+        gw, aw = self.grad_slot(prefix + ".ln.w")
+        gb, ab = self.grad_slot(prefix + ".ln.b")
+        tt = tabs[2]                                   # zeroed above unless accumulating: rows 0/1 always add
+        self.colsums.add(partial, (gw, gb, tt[0]), nblk, 4 * H, H, 3, (aw, ab, True))
+        if tt.shape[0] > 1:
+            self.colsums.add(partial[3 * H:], (tt[1], None, None), nblk, 4 * H, H, 1, (True, False, False))
 
     def img_embed(self, x, loc, cfg):
         M, H = x.M, cfg.v_hidden_size
@@ -483,17 +530,21 @@ class Engine(object):
         c = self.enc_cfg
         H, Hv, Hb, nh = c.hidden_size, c.v_hidden_size, c.bi_hidden_size, c.bi_num_attention_heads
         d = Hb // nh
-        qkv1 = self.lin(xv, p + ".qkv1.w", p + ".qkv1.b", 3 * Hb, Hv)
+        with self.on("v"):
+            qkv1 = self.lin(xv, p + ".qkv1.w", p + ".qkv1.b", 3 * Hb, Hv)
         qkv2 = self.lin(xt, p + ".qkv2.w", p + ".qkv2.b", 3 * Hb, H)
+        self.sync("t", "v")
+        self.sync("v", "t")
         ctx1 = self.attn((qkv2, 0), (qkv1, Hb), (qkv1, 2 * Hb), Bn, nh, T, R, d, I["vmask"], False, -10000.0,
                          c.v_attention_probs_dropout_prob)
-        ctx2 = self.attn((qkv1, 0), (qkv2, Hb), (qkv2, 2 * Hb), Bn, nh, R, T, d, I["tmask"], False, -10000.0,
-                         c.attention_probs_dropout_prob)
-        hv = self.lin(ctx2, p + ".d1.w", p + ".d1.b", Hv, Hb)
+        with self.on("v"):
+            ctx2 = self.attn((qkv1, 0), (qkv2, Hb), (qkv2, 2 * Hb), Bn, nh, R, T, d, I["tmask"], False, -10000.0,
+                             c.attention_probs_dropout_prob)
+            hv = self.lin(ctx2, p + ".d1.w", p + ".d1.b", Hv, Hb)
+            av = self.ln(hv, xv, p + ".ln1.w", p + ".ln1.b", Hv, c.v_hidden_dropout_prob, p + ".d1.b")
+            ov = self.ffn_block(p, av, Hv, c.v_intermediate_size, c.v_hidden_dropout_prob, ".vfi", ".vfo", ".vln")
         ht = self.lin(ctx1, p + ".d2.w", p + ".d2.b", H, Hb)
-        av = self.ln(hv, xv, p + ".ln1.w", p + ".ln1.b", Hv, c.v_hidden_dropout_prob, p + ".d1.b")
         at = self.ln(ht, xt, p + ".ln2.w", p + ".ln2.b", H, c.hidden_dropout_prob, p + ".d2.b")
-        ov = self.ffn_block(p, av, Hv, c.v_intermediate_size, c.v_hidden_dropout_prob, ".vfi", ".vfo", ".vln")
         ot = self.ffn_block(p, at, H, c.intermediate_size, c.hidden_dropout_prob, ".tfi", ".tfo", ".tln")
         return ov, ot
 
@@ -503,8 +554,10 @@ class Engine(object):
         Bn, T, R = I["B"], I["T"], I["R"]
         xt = self.embed("emb", I["ids"], I["segs"], Bn, T, c)
         f = Act(I["feats"], Bn * R, c.v_feature_size)
-        g0 = self.lin(f, "vemb.img.w", "vemb.img.b", c.v_hidden_size, c.v_feature_size, need_dx=I["feats_grad"])
-        xv = self.img_embed(g0, I["loc"], c)
+        self.sync("v", "t")                   # fork: the vision stream starts once the inputs are staged
+        with self.on("v"):
+            g0 = self.lin(f, "vemb.img.w", "vemb.img.b", c.v_hidden_size, c.v_feature_size, need_dx=I["feats_grad"])
+            xv = self.img_embed(g0, I["loc"], c)
         I["feats_act"] = f
         for kind, i in encoder_schedule(c):
             self.mark((kind, i))
@@ -515,11 +568,13 @@ class Engine(object):
                 xt = self.ffn_block(p, x1, c.hidden_size, c.intermediate_size, c.hidden_dropout_prob)
             elif kind == "v":
                 p = "v%d" % i
-                x1 = self.self_block(p, xv, Bn, R, c.v_hidden_size, c.v_num_attention_heads, I["vmask"],
-                                     c.v_attention_probs_dropout_prob, c.v_hidden_dropout_prob)
-                xv = self.ffn_block(p, x1, c.v_hidden_size, c.v_intermediate_size, c.v_hidden_dropout_prob)
+                with self.on("v"):
+                    x1 = self.self_block(p, xv, Bn, R, c.v_hidden_size, c.v_num_attention_heads, I["vmask"],
+                                         c.v_attention_probs_dropout_prob, c.v_hidden_dropout_prob)
+                    xv = self.ffn_block(p, x1, c.v_hidden_size, c.v_intermediate_size, c.v_hidden_dropout_prob)
             else:
                 xv, xt = self.conn_layer("c%d" % i, xv, xt, Bn, R, T, I)
+        self.sync("t", "v")                   # join before VLFusion
         return xt, xv
 
     def fusion(self, xt, xv, I):
@@ -619,6 +674,8 @@ class Engine(object):
         self.prepare(device)
         self.arena.reset()
         self.tape, self.rec = [], record
+        self.tag = "t"
+        self.main = torch.cuda.current_stream()
         self._site = 0
         self.train = bool(self.model.training)
         if self.train:
@@ -673,8 +730,17 @@ class Engine(object):
         logits.g = self.buf(st["Md"], flat.Vp)
         gs = gloss.reshape(1).float().contiguous() if gloss is not None else None
         ops.ce_bwd(logits.t, st["lab"], st["lse"], st["stats"], gs, True, st["Md"], st["V"], logits.g, ignore_index=st["pad"])
-        for fn in reversed(st["tape"]):
-            fn()
+        self.main, self.tag = torch.cuda.current_stream(), "t"
+        for tag, fn in reversed(st["tape"]):
+            if tag == "sync":
+                self._wait(*fn)
+            elif tag == "v" and self.use_streams:
+                with torch.cuda.stream(self.side):
+                    fn()
+            else:
+                fn()
+        if self.use_streams:
+            self._wait("t", "v")
         self.wgrads.flush()
         self.colsums.flush()
         if self.grad_hook is not None:

@@ -99,13 +99,18 @@ class FusedAdamW(object):
             raise RuntimeError("FusedAdamW.step() before the first forward/backward")
         if not self._built or self._flat_id != id(flat.P):
             self._build()
-        self._upload_hp()
+        self._upload_hp()                 # host->device only when the learning rate changed (never inside a captured graph)
         self.opt_step += 1
-        self.step_dev.fill_(float(self.opt_step))
+        self.step_dev.add_(1.0)           # device-side step counter: correct under hipGraph replay
         ops.adamw(flat.P, flat.G, self.m, self.v, flat.S, self.seg_end, self.hp, self.step_dev, self.betas[0],
                   self.betas[1], self.eps, self.grad_scale)
         if flat.S is not None:
             flat.shadow_version = flat.version()
+
+    def upload_lr(self):
+        """Refresh the device learning-rate table (call between hipGraph replays when the schedule moved)."""
+        if self._built:
+            self._upload_hp()
 
     def scheduler_step(self):
         self.sched_step += 1

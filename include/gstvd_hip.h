@@ -107,7 +107,9 @@ int gstvd_ln_fwd(const gstvd_ln_t* p, gstvd_stream_t s);
 /* backward: dh = LN'(dy) ; dres = dh ; dx = drop_pre'(dh).
  * partial: fp32 [nblk, 3, H] scratch (nblk = gstvd_ln_bwd_blocks(M)) receiving per-block column sums of
  * (dy*xhat, dy, dx); reduce them with gstvd_colsum_partials.
- * EMBED mode scatters dh into dword/dpos/dtt/dtt_ext (fp32, atomic add) instead of writing dres/dx. */
+ * EMBED mode scatters dh into dword/dpos (and dtt/dtt_ext for segment ids >= 2) with fp32 atomic adds instead of
+ * writing dres/dx; its partial is [nblk, 4, H]: (dy*xhat, dy, dh of segment-0 rows, dh of segment-1 rows) -- the
+ * caller adds vectors 2 and 3 to dtt rows 0 and 1 (no atomics onto those two hot rows). */
 typedef struct {
   gstvd_ln_t f;                 /* the forward descriptor (y unused) */
   const void* dy; int64_t lddy;

@@ -190,11 +190,14 @@ def test_ln_embed_fwd_bwd(dtype):
     dy = rnd(M, H, dtype=dtype, seed=36)
     yref.backward(dy.float())
     nblk = o.ln_bwd_blocks(M)
-    partial = torch.empty(nblk, 3, H, device=DEV)
+    partial = torch.empty(nblk, 4, H, device=DEV)
     dws = [torch.zeros_like(t) for t in (word, pos, tt, tte)]
     o.ln_bwd(kw, dy, partial, dword=dws[0], dpos=dws[1], dtt=dws[2], dtt_ext=dws[3])
     dg, db = torch.empty(H, device=DEV), torch.empty(H, device=DEV)
-    o.colsum_partials(partial, nblk, 2, H, dg, db, None, accumulate=False)
+    batch = o.ColsumBatch(DEV)
+    batch.add(partial.view(-1), (dg, db, dws[2][0]), nblk, 4 * H, H, 3, (False, False, True))
+    batch.add(partial.view(-1)[3 * H:], (dws[2][1], None, None), nblk, 4 * H, H, 1, (True, False, False))
+    batch.flush()
     for name, got, ref in zip(("dword", "dpos", "dtt", "dtt_ext"), dws, ws[:4]):
         check("embed_" + name, got, ref.grad, dtype, 3.0)
     check("embed_dgamma", dg, ws[4].grad, dtype, 3.0)
