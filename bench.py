@@ -128,6 +128,7 @@ def main():
     ap.add_argument("--breakdown-json", default=None, help="write the per-kernel breakdown here")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the whole train step as one hipGraph (auto: on for 1 GPU, off for N>1)")
+    ap.add_argument("--chunk-melems", type=int, default=40, help="backward-pipeline slice size in Mi elements")
     ap.add_argument("--no-streams", action="store_true", help="run the vision stream on the main HIP stream")
     args = ap.parse_args()
 
@@ -146,7 +147,7 @@ def main():
 
     from gst_visdial_amd import ops
     from gst_visdial_amd.optim import FusedAdamW
-    from gst_visdial_amd.dp import GradSync
+    from gst_visdial_amd.pipeline import BackwardPipeline
 
     B, T, R, U, F = args.rows_per_gpu, args.seq_len, 37, 25, 2048
     model, params = build_model(device, args.precision, seed=1234, streams=not args.no_streams)      # same init on every rank
@@ -154,15 +155,14 @@ def main():
     model.train()
     batch = synthetic_rows(B, T, R, U, F, V, 1234 + rank, device)
     opt = FusedAdamW(model, lr=2e-5, warmup_steps=1500, t_total=100000)
-    sync = GradSync(model.engine, bucket_elems=64 << 20, compress=args.grad_compress)
-    opt.grad_scale = 1.0 / world
+    # gradients are finalised slice by slice on a third stream during backward: grouped wgrad GEMMs -> column
+    # reductions -> (N>1) RCCL all-reduce of the slice -> fused AdamW on the slice
+    pipe = BackwardPipeline(model.engine, optimizer=opt, chunk_elems=args.chunk_melems << 20, compress=args.grad_compress)
 
     def step():
-        sync.begin() if world > 1 else None
         loss, _ = model(**batch)
-        loss.backward()
-        sync.finish()
-        opt.step()
+        loss.backward()          # includes the pipelined all-reduce + AdamW
+        opt.step()               # no-op marker: the update was applied during backward
         opt.scheduler_step()
         opt.zero_grad()
         return loss

@@ -58,6 +58,10 @@ class ColsumEntry(C.Structure):
                 ("nvec", _i32), ("accumulate", _i32 * 3), ("blk0", _i32)]
 
 
+class SlabEntry(C.Structure):
+    _fields_ = [("x", _vp), ("scratch", _vp), ("ldx", _i64), ("M", _i64), ("N", _i64), ("blk0", _i32), ("pad_", _i32)]
+
+
 # name -> (restype, argtypes); every symbol include/gstvd_hip.h declares
 SIGNATURES = {
     "gstvd_abi_version": (_i32, []),
@@ -70,6 +74,7 @@ SIGNATURES = {
     "gstvd_ln_bwd": (_i32, [C.POINTER(LnBwdDesc), _vp]),
     "gstvd_colsum_partials": (_i32, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _i32, _vp]),
     "gstvd_colsum_batched": (_i32, [_vp, _i64, _i64, _vp]),
+    "gstvd_colsum_slabs_batched": (_i32, [_vp, _i64, _i64, _i32, _vp]),
     "gstvd_colsum_slabs": (_i32, [_vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp]),
     "gstvd_colsum": (_i32, [_vp, _i64, _i64, _i64, _i32, _vp, _vp, _i64, _i32, _vp]),
     "gstvd_locgrad": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _vp, _i32, _vp]),
@@ -83,7 +88,7 @@ SIGNATURES = {
     "gstvd_scale": (_i32, [_vp, _vp, _i64, _vp]),
     "gstvd_rng_advance": (_i32, [_vp, _vp]),
     "gstvd_dropout_mask": (_i32, [_vp, _i64, _f32, _u32, _vp, _vp]),
-    "gstvd_adamw": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _f32, _f32, _f32, _vp, _f32, _vp]),
+    "gstvd_adamw": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _f32, _f32, _f32, _vp, _f32, _i64, _vp]),
 }
 
 _STATUS = {-1: "GSTVD_E_DTYPE", -2: "GSTVD_E_SHAPE", -3: "GSTVD_E_ALIGN", -4: "GSTVD_E_NULL", -5: "GSTVD_E_UNSUPPORTED"}

@@ -252,6 +252,34 @@ __global__ __launch_bounds__(256) void colsum_slab_kernel(const T* x, int64_t ld
     *(f32x4*)(partial + (int64_t)blockIdx.y * N + c) = a;
   }
 }
+// table-driven form of the slab stage: every pending bias-gradient column sum of a backward pass in one launch
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_slab_batched_kernel(const gstvd_slab_entry_t* tab, int nent) {
+  __shared__ f32x4 red[4][64];
+  int lo = 0, hi = nent - 1;
+  const int b = blockIdx.x;
+  while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (tab[mid].blk0 <= b) lo = mid; else hi = mid - 1; }
+  const gstvd_slab_entry_t e = tab[lo];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ncb = (int)((e.N + 255) / 256), local = b - e.blk0;
+  const int64_t c = (int64_t)(local % ncb) * 256 + lane * 4, slab = local / ncb, r0 = slab * 64;
+  const T* x = (const T*)e.x;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  if (c < e.N) {
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+      int64_t r = r0 + wave + 4 * i;
+      if (r < e.M) a += ld4(x + r * e.ldx + c);
+    }
+  }
+  red[wave][lane] = a;
+  __syncthreads();
+  if (wave == 0 && c < e.N) {
+    a = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    *(f32x4*)(e.scratch + slab * e.N + c) = a;
+  }
+}
+
 // stage 2: out[c] (+)= sum_s partial[s][c]
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* partial, int64_t nslab, int64_t N, float* out, int accumulate) {
   __shared__ float red[4][64];
@@ -413,6 +441,18 @@ extern "C" int gstvd_colsum_slabs(const void* x, int64_t ldx, int64_t M, int64_t
   dim3 grid((unsigned)((N + 255) / 256), (unsigned)nslab);
   if (dtype == GSTVD_BF16) hipLaunchKernelGGL(colsum_slab_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)x, ldx, M, N, scratch);
   else if (dtype == GSTVD_F32) hipLaunchKernelGGL(colsum_slab_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ldx, M, N, scratch);
+  else return GSTVD_E_DTYPE;
+  GSTVD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gstvd_colsum_slabs_batched(const gstvd_slab_entry_t* table_dev, int64_t nent, int64_t total_blocks, int32_t dtype,
+                                          gstvd_stream_t stream) {
+  if (!table_dev) return GSTVD_E_NULL;
+  if (nent <= 0 || total_blocks <= 0) return GSTVD_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == GSTVD_BF16) hipLaunchKernelGGL(colsum_slab_batched_kernel<bf16>, dim3((unsigned)total_blocks), dim3(256), 0, s, table_dev, (int)nent);
+  else if (dtype == GSTVD_F32) hipLaunchKernelGGL(colsum_slab_batched_kernel<float>, dim3((unsigned)total_blocks), dim3(256), 0, s, table_dev, (int)nent);
   else return GSTVD_E_DTYPE;
   GSTVD_LAUNCH_CHECK();
   return 0;

@@ -123,8 +123,9 @@ __global__ void dropout_mask_kernel(float* out, int64_t n, float p, uint32_t sit
 // (the flat layout aligns every tensor to 64 elements), so one lookup serves a 16-byte vector.
 __global__ __launch_bounds__(256) void adamw_kernel(float* param, const float* grad, float* m, float* v, bf16* shadow, int64_t n,
                                                     const int64_t* seg_end, const float* hp, int64_t nseg, float b1, float b2,
-                                                    float eps, const float* step, float gscale) {
-  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+                                                    float eps, const float* step, float gscale, int64_t base) {
+  // the launch covers flat elements [base, n) of the buffers (pointers are the buffers' starts); segment ends are absolute
+  const int64_t i = base + ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= n) return;
   int64_t lo = 0, hi = nseg - 1;                       // first segment whose end > i
   while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (seg_end[mid] > i) hi = mid; else lo = mid + 1; }
@@ -274,11 +275,11 @@ extern "C" int gstvd_dropout_mask(float* out, int64_t n, float p, uint32_t site,
 
 extern "C" int gstvd_adamw(float* param, const float* grad, float* m, float* v, void* shadow_bf16, int64_t n,
                            const int64_t* seg_end, const float* hp, int64_t nseg, float beta1, float beta2, float eps,
-                           const float* step, float grad_scale, gstvd_stream_t stream) {
+                           const float* step, float grad_scale, int64_t begin, gstvd_stream_t stream) {
   if (!param || !grad || !m || !v || !seg_end || !hp || !step) return GSTVD_E_NULL;
-  if (n <= 0 || nseg <= 0) return GSTVD_E_SHAPE;
-  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v,
-                     (bf16*)shadow_bf16, n, seg_end, hp, nseg, beta1, beta2, eps, step, grad_scale);
+  if (n <= 0 || nseg <= 0 || begin < 0 || begin >= n || (begin % 4)) return GSTVD_E_SHAPE;
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n - begin + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v,
+                     (bf16*)shadow_bf16, n, seg_end, hp, nseg, beta1, beta2, eps, step, grad_scale, begin);
   GSTVD_LAUNCH_CHECK();
   return 0;
 }

@@ -263,6 +263,7 @@ class Engine(object):
         self.rng = None
         self.anchor = None
         self.grad_hook = None          # callable(offset): every gradient at flat offset >= `offset` is final
+        self.pipe = None               # BackwardPipeline (pipeline.py): slice-wise wgrad / all-reduce / AdamW on the aux stream
         self.tape, self.rec = [], False
         self.accumulate, self.written = False, set()
         self.stats = {}
@@ -289,6 +290,8 @@ class Engine(object):
             self.rng = ops.Rng(device, seed=int(self.model.params.get("amd_seed", 0)))
             self.anchor = torch.zeros(1, device=device, requires_grad=True)
             self.side = torch.cuda.Stream(device=device)
+            self.aux = torch.cuda.Stream(device=device)
+            self.aux_busy = False
             self.colsums = ops.ColsumBatch(device)
             self.wgrads = ops.GemmGroup(device, a_km=True, b_km=True)
         self.flat.refresh_shadow()
@@ -328,16 +331,38 @@ class Engine(object):
             self.tape.append((self.tag, fn))
 
     def mark(self, key):
-        if self.rec and self.grad_hook is not None:
+        if self.rec and (self.grad_hook is not None or self.pipe is not None):
             off = self.flat.marks[key]
             self.tape.append(("t", lambda: self._hook(off)))
 
     def _hook(self, off):
+        """Backward reached flat offset `off`: every gradient at offset >= off has been produced or queued."""
+        if self.pipe is not None:
+            if self.pipe.ready(off):
+                self._emit(off)
+            return
         if self.use_streams:
             self._wait("t", "v")
+        if self.aux_busy:
+            ev = torch.cuda.Event()
+            ev.record(self.aux)
+            self.main.wait_event(ev)
+            self.aux_busy = False
         self.wgrads.flush()           # weight / bias / LayerNorm gradients of the finished region must be final first
         self.colsums.flush()
         self.grad_hook(off)
+
+    def _emit(self, off):
+        """Hand the finished slice [off, pipe.hi) to the backward pipeline on the auxiliary stream."""
+        for src in ([self.main, self.side] if self.use_streams else [self.main]):
+            ev = torch.cuda.Event()
+            ev.record(src)
+            self.aux.wait_event(ev)
+        with torch.cuda.stream(self.aux):
+            self.wgrads.flush()
+            self.colsums.flush()
+            self.pipe.run_slice(off, self.pipe.hi)
+        self.aux_busy = True
 
     # -- two HIP streams: the vision stream's skinny (M = B*37) kernels run beside the text stream's --------------
     class _On(object):
@@ -358,6 +383,17 @@ class Engine(object):
 
     def on(self, tag):
         return Engine._On(self, tag)
+
+    def _flush_aux(self):
+        """Run the queued (decoder + LM head) weight-gradient group and column reductions on a third stream so they
+        overlap the encoder's backward chain; joined back before the final flush."""
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        self.aux.wait_event(ev)
+        with torch.cuda.stream(self.aux):
+            self.wgrads.flush()
+            self.colsums.flush()
+        self.aux_busy = True
 
     def _stream_of(self, tag):
         return self.side if tag == "v" else self.main
@@ -394,10 +430,8 @@ class Engine(object):
         self.wgrads.add(dy, x.t, gw, N, K, M, acc)       # deferred: all weight-gradient GEMMs run as one grouped launch
         if not y.bias_done:
             gb, accb = self.grad_slot(b)
-            nslab = (M + 63) // 64
-            scratch = self.vec(nslab * N)
-            ops.colsum_slabs(dy, M, N, scratch)
-            self.colsums.add(scratch, (gb, None, None), nslab, N, N, 1, (accb, False, False))
+            scratch = self.vec(((M + 63) // 64) * N)
+            self.colsums.add_slabs(dy, M, N, scratch, gb, accb)
         if need_dx:
             add = x.g
             if x.g is None:
@@ -609,6 +643,8 @@ class Engine(object):
         d = H // nh
         eps = c.layer_norm_eps
         self.mark("dec")
+        if self.rec and self.use_streams and self.grad_hook is None and self.pipe is None:
+            self.tape.append(("t", self._flush_aux))      # backward: the decoder's gradients are complete here
         if kv is None:
             kv = self.lin(enc, "dec.ckv.w", "dec.ckv.b", 2 * L * H, H)
         y = self.embed("emb" if self.flat.dec_emb is self.flat.enc_emb else "demb", I["dec_ids"], None, Bn, U, c)
@@ -731,6 +767,8 @@ class Engine(object):
         gs = gloss.reshape(1).float().contiguous() if gloss is not None else None
         ops.ce_bwd(logits.t, st["lab"], st["lse"], st["stats"], gs, True, st["Md"], st["V"], logits.g, ignore_index=st["pad"])
         self.main, self.tag = torch.cuda.current_stream(), "t"
+        if self.pipe is not None:
+            self.pipe.begin()
         for tag, fn in reversed(st["tape"]):
             if tag == "sync":
                 self._wait(*fn)
@@ -741,6 +779,15 @@ class Engine(object):
                 fn()
         if self.use_streams:
             self._wait("t", "v")
+        if self.pipe is not None:
+            if self.pipe.hi > 0:
+                self._emit(0)
+            self.pipe.end()
+        if self.aux_busy:
+            ev = torch.cuda.Event()
+            ev.record(self.aux)
+            self.main.wait_event(ev)
+            self.aux_busy = False
         self.wgrads.flush()
         self.colsums.flush()
         if self.grad_hook is not None:

@@ -276,7 +276,16 @@ class ColsumBatch(object):
         self.device = device
         self.entries = []            # (partial_ptr, (out0,out1,out2 ptrs), nblk, stride, H, nvec, (acc0,acc1,acc2))
         self.targets, self.keep = set(), []
+        self.slabs, self.slab_dtype, self.slab_cache = [], None, {}
         self.cache = {}
+
+    def add_slabs(self, x, M, N, scratch, out, accumulate):
+        """out[c] (+)= sum_m x[m, c]: queue the 64-row slab stage and the final reduction (both batched at flush)."""
+        nslab = (M + 63) // 64
+        self.slabs.append((x.data_ptr(), scratch.data_ptr(), x.stride(-2), M, N))
+        self.slab_dtype = dt(x)
+        self.keep.append((x, scratch))
+        self.add(scratch, (out, None, None), nslab, N, N, 1, (accumulate, False, False))
 
     def add(self, partial, outs, nblk, stride, H, nvec, accs):
         ptrs = [o.data_ptr() for o in outs if o is not None]
@@ -288,11 +297,33 @@ class ColsumBatch(object):
                              nvec, tuple(int(bool(a)) for a in accs)))
 
     def reset(self):
-        self.entries, self.targets, self.keep = [], set(), []
+        self.entries, self.targets, self.keep, self.slabs = [], set(), [], []
+
+    def _flush_slabs(self):
+        key = tuple(self.slabs)
+        hit = self.slab_cache.get(key)
+        if hit is None:
+            arr = (L.SlabEntry * len(key))()
+            blk = 0
+            for e, (xp, sp, ldx, M, N) in zip(arr, key):
+                e.x, e.scratch, e.ldx, e.M, e.N, e.blk0 = xp, sp, ldx, M, N, blk
+                blk += ((M + 63) // 64) * ((N + 255) // 256)
+            hit = (torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device), len(key), blk)
+            if len(self.slab_cache) > 64:
+                self.slab_cache.clear()
+            self.slab_cache[key] = hit
+        tab, n, blocks = hit
+        lib = L.load()
+        e0 = _prof_begin()
+        L.check("gstvd_colsum_slabs_batched", lib.gstvd_colsum_slabs_batched(tab.data_ptr(), n, blocks, self.slab_dtype, _stream()))
+        _prof_end(e0, "colsum_slabs_batched", 0.0, 0.0)
+        self.slabs = []
 
     def flush(self):
         if not self.entries:
             return
+        if self.slabs:
+            self._flush_slabs()
         key = tuple(self.entries)
         hit = self.cache.get(key)
         if hit is None:
@@ -403,9 +434,11 @@ def dropout_mask(n, p, site, rng, device):
     return out
 
 
-def adamw(param, grad, m, v, shadow, seg_end, hp, step, beta1=0.9, beta2=0.999, eps=1e-6, grad_scale=1.0):
+def adamw(param, grad, m, v, shadow, seg_end, hp, step, beta1=0.9, beta2=0.999, eps=1e-6, grad_scale=1.0, begin=0, end=None):
+    """Fused AdamW over flat elements [begin, end) of the buffers."""
     lib = L.load()
+    n = param.numel() if end is None else end
     e0 = _prof_begin()
-    L.check("gstvd_adamw", lib.gstvd_adamw(_p(param), _p(grad), _p(m), _p(v), _p(shadow), param.numel(), _p(seg_end), _p(hp),
-                                           seg_end.numel(), beta1, beta2, eps, _p(step), grad_scale, _stream()))
-    _prof_end(e0, "adamw", 0.0, param.numel() * (30.0 if shadow is not None else 28.0))
+    L.check("gstvd_adamw", lib.gstvd_adamw(_p(param), _p(grad), _p(m), _p(v), _p(shadow), n, _p(seg_end), _p(hp),
+                                           seg_end.numel(), beta1, beta2, eps, _p(step), grad_scale, begin, _stream()))
+    _prof_end(e0, "adamw", 0.0, (n - begin) * (30.0 if shadow is not None else 28.0))

@@ -36,6 +36,7 @@ class FusedAdamW(object):
         self.opt_step = 0            # optimizer.step() count
         self.grad_scale = 1.0        # e.g. 1/world_size after a summing all-reduce
         self._built = False
+        self._applied_in_backward = False
 
     def _names(self):
         """Parameter names relative to the encoder / decoder module, as train_gen.py:211,229 sees them."""
@@ -92,20 +93,33 @@ class FusedAdamW(object):
         self.hp.copy_(self.hp_host, non_blocking=True)
         self._last_lr_key = key
 
-    def step(self):
-        """optimizer.step(): one fused launch over the flat buffers."""
+    def begin_step(self):
+        """Advance the step counter (device resident: correct under hipGraph replay) and make sure the lr table is current."""
         flat = self.engine.flat
         if flat is None or flat.P is None:
-            raise RuntimeError("FusedAdamW.step() before the first forward/backward")
+            raise RuntimeError("FusedAdamW before the first forward")
         if not self._built or self._flat_id != id(flat.P):
             self._build()
         self._upload_hp()                 # host->device only when the learning rate changed (never inside a captured graph)
         self.opt_step += 1
-        self.step_dev.add_(1.0)           # device-side step counter: correct under hipGraph replay
+        self.step_dev.add_(1.0)
+
+    def apply_range(self, lo, hi):
+        """AdamW on flat elements [lo, hi) -- used slice by slice by the backward pipeline."""
+        flat = self.engine.flat
         ops.adamw(flat.P, flat.G, self.m, self.v, flat.S, self.seg_end, self.hp, self.step_dev, self.betas[0],
-                  self.betas[1], self.eps, self.grad_scale)
+                  self.betas[1], self.eps, self.grad_scale, begin=lo, end=hi)
         if flat.S is not None:
             flat.shadow_version = flat.version()
+
+    def step(self):
+        """optimizer.step(): one fused launch over the flat buffers -- or nothing, when a BackwardPipeline already
+        applied this step's update slice by slice during loss.backward()."""
+        if self._applied_in_backward:
+            self._applied_in_backward = False
+            return
+        self.begin_step()
+        self.apply_range(0, self.engine.flat.n_live)
 
     def upload_lr(self):
         """Refresh the device learning-rate table (call between hipGraph replays when the schedule moved)."""

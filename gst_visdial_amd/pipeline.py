@@ -1,0 +1,63 @@
+"""Backward pipeline: finalise gradients slice by slice on a third HIP stream while backward is still running.
+
+Backward completes the flat gradient buffer from its end (LM head, decoder) to its start (embeddings).  Whenever
+a contiguous slice [lo, hi) of at least `chunk_elems` elements is complete the engine hands it to this object,
+which -- on the engine's auxiliary stream, i.e. concurrently with the remaining backward kernels -- runs
+
+    1. the deferred weight-gradient GEMMs of the slice (one grouped launch) and its column reductions,
+    2. for N > 1: a RCCL sum all-reduce of G[lo:hi] (one large contiguous collective per slice; xGMI links are
+       point to point, so few large messages beat many small ones),
+    3. the fused AdamW update of P[lo:hi] (+ bf16 shadow weights), with the 1/N scale folded in.
+
+This is the MI355X-native replacement of nn.DataParallel's per-step parameter broadcast + gradient reduce-add
+(train_gen.py:295,324) and of the serial optimizer.step() (train_gen.py:326-329).  loss = mean over ranks of the
+per-rank token mean, exactly DataParallel's gather + .mean() (train_gen.py:134-135).
+"""
+import torch
+import torch.distributed as dist
+
+
+class BackwardPipeline(object):
+    def __init__(self, engine, optimizer=None, group=None, chunk_elems=40 << 20, compress=None):
+        self.engine, self.opt, self.group = engine, optimizer, group
+        self.chunk = chunk_elems
+        self.compress = compress
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.hi = None
+        self.slices = []
+        if optimizer is not None:
+            optimizer.grad_scale = 1.0 / self.world
+        engine.pipe = self
+
+    def begin(self):
+        """Called by the engine at the start of backward (main stream)."""
+        self.hi = self.engine.flat.n_live
+        self.slices = []
+        if self.opt is not None:
+            self.opt.begin_step()
+
+    def ready(self, off):
+        """True when the completed region [off, hi) should be emitted now."""
+        return off < self.hi and ((self.hi - off) >= self.chunk or off == 0)
+
+    def run_slice(self, lo, hi):
+        """Runs on the auxiliary stream, after the slice's weight-gradient GEMMs and column reductions."""
+        flat = self.engine.flat
+        self.slices.append((lo, hi))
+        if self.world > 1:
+            sl = flat.G[lo:hi]
+            if self.compress == "bf16":
+                from . import ops
+                tmp = torch.empty(hi - lo, dtype=torch.bfloat16, device=sl.device)
+                ops.cast(sl, tmp)
+                dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group)
+                ops.cast(tmp, sl)
+            else:
+                dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group)
+        if self.opt is not None:
+            self.opt.apply_range(lo, hi)
+        self.hi = lo
+
+    def end(self):
+        if self.opt is not None:
+            self.opt._applied_in_backward = True

@@ -134,6 +134,11 @@ typedef struct {
   int32_t nvec, accumulate[3], blk0;
 } gstvd_colsum_entry_t;
 int gstvd_colsum_batched(const gstvd_colsum_entry_t* table_dev, int64_t nent, int64_t total_blocks, gstvd_stream_t s);
+/* table-driven stage 1: entry i owns blocks [blk0_i, blk0_{i+1}), ceil(M/64) * ceil(N/256) blocks each;
+ * scratch[slab, N] = sums over rows [64*slab, 64*slab+64) of x[M, N] (row stride ldx, all entries of one dtype) */
+typedef struct { const void* x; float* scratch; int64_t ldx, M, N; int32_t blk0, pad_; } gstvd_slab_entry_t;
+int gstvd_colsum_slabs_batched(const gstvd_slab_entry_t* table_dev, int64_t nent, int64_t total_blocks, int32_t dtype,
+                               gstvd_stream_t s);
 /* stage 1 of a plain column sum: scratch[slab, N] = per-64-row-slab sums of x[M, N] (reduce with the batched form) */
 int gstvd_colsum_slabs(const void* x, int64_t ldx, int64_t M, int64_t N, int32_t dtype, float* scratch,
                        int64_t scratch_elems, gstvd_stream_t s);
@@ -201,10 +206,12 @@ int gstvd_dropout_mask(float* out, int64_t n, float p, uint32_t site, const uint
 /* fused AdamW over flat fp32 buffers with pytorch_transformers-1.2.0 semantics (train_gen.py:16,247:
  * eps inside sqrt(v)+eps, bias correction, decoupled decay applied after the update) and, optionally,
  * refresh of the bf16 shadow weights in the same pass.  lr/wd are per-element-segment tables:
- * seg_end[i] is the exclusive end offset of segment i; hp[2*i] = lr, hp[2*i+1] = weight decay. */
+ * seg_end[i] is the exclusive end offset of segment i; hp[2*i] = lr, hp[2*i+1] = weight decay (lr 0 = skip).
+ * The call updates flat elements [begin, n): the backward pipeline applies the optimizer slice by slice, as soon
+ * as a slice's gradients are final, overlapped with the rest of backward. */
 int gstvd_adamw(float* param, const float* grad, float* m, float* v, void* shadow_bf16, int64_t n,
                 const int64_t* seg_end, const float* hp, int64_t nseg, float beta1, float beta2, float eps,
-                const float* step /* device scalar, 1-based */, float grad_scale, gstvd_stream_t s);
+                const float* step /* device scalar, 1-based */, float grad_scale, int64_t begin, gstvd_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -76,3 +76,45 @@ def test_single_process_installs_no_hook():
     s = GradSync(eng)
     assert eng.grad_hook is None
     s.begin(); s.finish()
+
+
+def _pipe_worker(rank, world, port, n, marks, chunk, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gst_visdial_amd.pipeline import BackwardPipeline
+    eng = _Engine(n, rank)
+    eng.pipe = None
+    expect = sum(_Flat(n, r).G for r in range(world))
+    pipe = BackwardPipeline(eng, optimizer=None, chunk_elems=chunk)
+    pipe.begin()
+    for off in marks:                        # what engine._hook does at every backward watermark
+        if pipe.ready(off):
+            pipe.run_slice(off, pipe.hi)
+    if pipe.hi > 0:
+        pipe.run_slice(0, pipe.hi)
+    pipe.end()
+    q.put((rank, torch.allclose(eng.flat.G, expect, atol=1e-6), pipe.slices))
+    dist.destroy_process_group()
+
+
+def test_backward_pipeline_slices_world2():
+    """BackwardPipeline (the path bench.py uses): one contiguous all-reduce per finished slice, world_size 2."""
+    n, chunk = 10000, 2500
+    marks = [9500, 9000, 7400, 7000, 4000, 3900, 1000, 64]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipe_worker, args=(r, 2, port, n, marks, chunk, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, slices in res:
+        assert ok
+        assert slices[0][1] == n and slices[-1][0] == 0
+        for (lo, hi), (lo2, hi2) in zip(slices, slices[1:]):
+            assert hi2 == lo
+        assert all(hi - lo >= chunk for lo, hi in slices[:-1])

@@ -214,3 +214,35 @@ def test_graph_replay_reproduces_eager_training_steps():
     for a, b in zip(le, lg):
         assert abs(a - b) < 2e-4 * max(1.0, abs(a)), (le, lg)
     assert maxerr(we, wg) < 1e-5
+
+
+def test_backward_pipeline_matches_plain_optimizer_step():
+    """Slice-wise wgrad / AdamW on the auxiliary stream during backward == backward followed by one AdamW launch."""
+    from gst_visdial_amd.optim import FusedAdamW
+    from gst_visdial_amd.pipeline import BackwardPipeline
+    s = sc()
+    g = load_npz("tiny_train.npz")
+
+    def run(pipelined):
+        model, params, cfg = s.build_tiny_model("fp32", DEV, seed=11)
+        model.train()
+        kw = s.golden_batch(g, DEV)
+        opt = FusedAdamW(model, lr=1e-3)
+        pipe = BackwardPipeline(model.engine, optimizer=opt, chunk_elems=100000) if pipelined else None
+        losses = []
+        for _ in range(3):
+            loss, _ = model(**kw)
+            loss.backward()
+            opt.step()
+            opt.zero_grad()
+            losses.append(loss.item())
+        if pipe is not None:
+            assert len(pipe.slices) >= 3 and pipe.slices[0][1] == model.engine.flat.n_live and pipe.slices[-1][0] == 0
+        torch.cuda.synchronize()
+        return losses, model.engine.flat.P.clone()
+
+    l0, p0 = run(False)
+    l1, p1 = run(True)
+    for a, b in zip(l0, l1):
+        assert abs(a - b) < 1e-4 * max(1.0, abs(a)), (l0, l1)
+    assert maxerr(p0, p1) < 1e-5
