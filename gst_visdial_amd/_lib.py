@@ -50,7 +50,7 @@ class AttnDesc(C.Structure):
                 ("B", _i32), ("nh", _i32), ("Lq", _i32), ("Lk", _i32), ("d", _i32), ("causal", _i32), ("dtype", _i32),
                 ("mask_neg", _f32), ("scale", _f32), ("dropout_p", _f32), ("site", _u32), ("rng", _vp),
                 ("dO", _vp), ("lddo", _i64), ("dQ", _vp), ("dK", _vp), ("dV", _vp),
-                ("lddq", _i64), ("lddk", _i64), ("lddv", _i64), ("delta", _vp)]
+                ("lddq", _i64), ("lddk", _i64), ("lddv", _i64), ("delta", _vp), ("kv_group", _i32)]
 
 
 class ColsumEntry(C.Structure):

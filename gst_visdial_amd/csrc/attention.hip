@@ -164,9 +164,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(gstvd_attn_t a) {
   const int b = blockIdx.z, h = blockIdx.y;
   const int q = blockIdx.x * 64 + wave * 16 + li;
   const bool qv = q < a.Lq;
+  const int bk = a.kv_group > 1 ? b / a.kv_group : b;       // batch row of the (possibly shared) keys / values
   const T* Qb = (const T*)a.Q + (int64_t)b * a.Lq * a.ldq + h * D;
-  const T* Kb = (const T*)a.K + (int64_t)b * a.Lk * a.ldk + h * D;
-  const T* Vb = (const T*)a.V + (int64_t)b * a.Lk * a.ldv + h * D;
+  const T* Kb = (const T*)a.K + (int64_t)bk * a.Lk * a.ldk + h * D;
+  const T* Vb = (const T*)a.V + (int64_t)bk * a.Lk * a.ldv + h * D;
   RowFrag<T, D> qf;
   qf.load(Qb + (int64_t)q * a.ldq, qv, g);
   const DropKey dk = make_drop(a.dropout_p, a.site, a.rng);
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(gstvd_attn_t a) {
     if (tid < 64) {
       const int key = c0 + tid;
       float mv = 2.f;
-      if (key < a.Lk) mv = (a.key_mask == nullptr || a.key_mask[(int64_t)b * a.Lk + key] != 0.f) ? 0.f : 1.f;
+      if (key < a.Lk) mv = (a.key_mask == nullptr || a.key_mask[(int64_t)bk * a.Lk + key] != 0.f) ? 0.f : 1.f;
       smask[tid] = mv;
     }
     __syncthreads();
@@ -395,6 +396,7 @@ static int attn_check(const gstvd_attn_t* a, bool bwd) {
   if ((a->ldq % ve) || (a->ldk % ve) || (a->ldv % ve) || (a->ldo % 4)) return GSTVD_E_ALIGN;
   if (((uintptr_t)a->Q | (uintptr_t)a->K | (uintptr_t)a->V | (uintptr_t)a->O) & 15) return GSTVD_E_ALIGN;
   if (bwd) {
+    if (a->kv_group > 1) return GSTVD_E_UNSUPPORTED;
     if (!a->dO || !a->dQ || !a->dK || !a->dV || !a->LSE || !a->delta) return GSTVD_E_NULL;
     if ((a->lddo % ve) || (a->lddq % 4) || (a->lddk % 4) || (a->lddv % 4)) return GSTVD_E_ALIGN;
   }

@@ -524,13 +524,14 @@ class Engine(object):
         gw, acc = self.grad_slot("vemb.loc.w")
         ops.locgrad(x.g, loc, M, H, gw, acc)
 
-    def attn(self, q, k, v, Bn, nh, Lq, Lk, d, key_mask, causal, neg, p):
+    def attn(self, q, k, v, Bn, nh, Lq, Lk, d, key_mask, causal, neg, p, kv_group=1):
         (qa, qc), (ka, kc), (va, vc) = q, k, v
         Hh = nh * d
         o = self.act(Bn * Lq, Hh)
         lse = self.vec(Bn * nh * Lq)
         a = ops.attn_desc(qa.t[:, qc:qc + Hh], ka.t[:, kc:kc + Hh], va.t[:, vc:vc + Hh], o.t, lse, key_mask, Bn, nh, Lq, Lk, d,
-                          causal=causal, mask_neg=neg, drop_p=p if self.train else 0.0, site=self.site(), rng=self.rng)
+                          causal=causal, mask_neg=neg, drop_p=p if self.train else 0.0, site=self.site(), rng=self.rng,
+                          kv_group=kv_group)
         ops.attn_fwd(a)
         self.push(lambda: self._attn_bwd(a, q, k, v, o, Bn, nh, Lq, Hh))
         return o
@@ -635,10 +636,11 @@ class Engine(object):
         self._lin_bwd(xv, yv, "vlf.v.w", "vlf.v.b", H, Hv, True)
         self._lin_bwd(xt, yt, "vlf.l.w", "vlf.l.b", H, H, True)
 
-    def decoder(self, enc, I, kv=None):
-        """BertGenerationEncoder + HF BertEncoder (self-attn -> cross-attn -> FFN, post-LN) + LM head."""
+    def decoder(self, enc, I, kv=None, kv_group=1):
+        """BertGenerationEncoder + HF BertEncoder (self-attn -> cross-attn -> FFN, post-LN) + LM head.
+        kv_group > 1 (inference): `kv_group` consecutive decoder rows attend to the same encoder row."""
         c = self.dec_cfg
-        Bn, U, S = I["B"], I["U"], I["R"] + I["T"]
+        Bn, U, S = I["B"] * kv_group, I["U"], I["R"] + I["T"]
         H, nh, L = c.hidden_size, c.num_attention_heads, c.num_hidden_layers
         d = H // nh
         eps = c.layer_norm_eps
@@ -658,7 +660,7 @@ class Engine(object):
             y1 = self.ln(ao, y, p + ".ln1.w", p + ".ln1.b", H, c.hidden_dropout_prob, p + ".ao.b", eps)
             q = self.lin(y1, p + ".cq.w", p + ".cq.b", H, H)
             ctx = self.attn((q, 0), (kv, 2 * i * H), (kv, (2 * i + 1) * H), Bn, nh, U, S, d, I["emask"], False, -1e9,
-                            c.attention_probs_dropout_prob)
+                            c.attention_probs_dropout_prob, kv_group=kv_group)
             co = self.lin(ctx, p + ".co.w", p + ".co.b", H, H)
             y2 = self.ln(co, y1, p + ".ln2.w", p + ".ln2.b", H, c.hidden_dropout_prob, p + ".co.b", eps)
             a = self.lin(y2, p + ".fi.w", p + ".fi.b", c.intermediate_size, H, gelu=True)
@@ -798,6 +800,37 @@ class Engine(object):
         if st["I"]["feats_grad"] and fa is not None and fa.g is not None:
             return fa.g.float()
         return None
+
+    # ------------------------------------------------------------------------------------------ candidate scoring
+    @torch.no_grad()
+    def score_candidates(self, feats, loc, img_mask, ids, segs, att_mask, dec_ids, dec_mask, group):
+        """evaluate_gen.py:45-106 without the 100x redundancy: the `group` answer candidates of a dialog round share ONE
+        encoder pass and ONE cross-attention K/V projection (the reference re-encodes the identical context per candidate).
+        Encoder-side tensors have E rows (one per dialog round), decoder-side tensors E*group rows ordered
+        [round, candidate].  Returns score[E*group] = sum_u [tgt != 0] log softmax(logits)[u, tgt], tgt = ids shifted left;
+        the decoder input is the eos->pad masked copy, as visual_dialog_decoder.py:53-57 makes it."""
+        dc = self.dec_cfg
+        E, rows = ids.shape[0], dec_ids.shape[0]
+        if rows != E * group:
+            raise GstvdError("score_candidates: %d decoder rows for %d encoder rows x %d candidates" % (rows, E, group))
+        self._begin(ids.device, False)
+        self.train = False
+        dec_in = dec_ids.masked_fill(dec_ids == dc.eos_token_id, dc.pad_token_id)
+        I = self._inputs(feats, loc, img_mask, ids, segs, att_mask, dec_in, dec_mask)
+        xt, xv = self.encoder(I)
+        enc = self.fusion(xt, xv, I)
+        L, H = dc.num_hidden_layers, dc.hidden_size
+        kv = self.lin(enc, "dec.ckv.w", "dec.ckv.b", 2 * L * H, H)
+        _, logits = self.decoder(enc, I, kv, kv_group=group)
+        U, V = I["U"], dc.vocab_size
+        Md = rows * U
+        tgt = dec_ids.new_zeros(dec_ids.shape)
+        tgt[:, :-1] = dec_ids[:, 1:]
+        row_loss, lse, stats = self.vec(Md), self.vec(Md), self.vec(4)
+        ops.ce_fwd(logits.t, tgt.contiguous().view(-1), Md, V, row_loss, lse, stats, ignore_index=dc.pad_token_id)
+        scores = torch.empty(rows, dtype=torch.float32, device=ids.device)
+        ops.answer_scores(logits.t, lse, dec_ids.contiguous(), rows, U, scores)
+        return scores
 
     # ------------------------------------------------------------------------------------------ sampling decode
     @torch.no_grad()

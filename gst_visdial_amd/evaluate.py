@@ -1,0 +1,57 @@
+"""Generative evaluation: the build's counterpart of evaluate_gen.evaluate (evaluate_gen.py:22-142).
+
+Same batch contract (per-dialog tensors [B, rounds, options, L] from the eval dataloader) and the
+same metrics; the model work differs in one way that does not change results: every (dialog, round) context is encoded
+ONCE and shared by its `options` answer candidates instead of being re-encoded per candidate."""
+import torch
+
+from .metrics import SparseGTMetrics, NDCG, scores_to_ranks
+
+
+def score_batch(model, batch, device, rounds_per_call=20):
+    """-> scores [B, rounds, options] (sum of target-token log-probabilities of every candidate answer)."""
+    ids = batch["enc_input_ids"]
+    B, R_, O = ids.shape[0], ids.shape[1], ids.shape[2]
+    T, U = ids.shape[-1], batch["dec_input_ids"].shape[-1]
+    # the `options` rows of a round carry the same context: take option 0 as the round's encoder input
+    enc_ids = ids[:, :, 0].reshape(B * R_, T)
+    enc_seg = batch["enc_segments"][:, :, 0].reshape(B * R_, T)
+    enc_att = batch["enc_att_mask"][:, :, 0].reshape(B * R_, T)
+    feat, loc, imask = batch["enc_image_feat"], batch["enc_image_loc"], batch["enc_image_mask"]
+    dial = torch.arange(B).repeat_interleave(R_)
+    dec_ids = batch["dec_input_ids"].reshape(B * R_, O, U)
+    dec_att = batch["dec_att_mask"].reshape(B * R_, O, U)
+    out = []
+    for s in range(0, B * R_, rounds_per_call):
+        e = slice(s, min(s + rounds_per_call, B * R_))
+        d = dial[e]
+        sc = model.score_candidates(feat[d].to(device), loc[d].to(device), imask[d].to(device), enc_ids[e].to(device),
+                                    enc_seg[e].to(device), enc_att[e].to(device), dec_ids[e].reshape(-1, U).to(device),
+                                    dec_att[e].reshape(-1, U).to(device), O)
+        out.append(sc)
+    return torch.cat(out).view(B, R_, O)
+
+
+@torch.no_grad()
+def evaluate(model, dataloader, params, mode="vd_eval_val"):
+    """Returns (ranks_json, metrics) like evaluate_gen.evaluate + its logged metric dict."""
+    sparse, ndcg, ranks_json = SparseGTMetrics(), NDCG(), []
+    model.eval()
+    device = params["device"]
+    for batch in dataloader:
+        scores = score_batch(model, batch, device)
+        if mode == "vd_eval_val":
+            sparse.observe(scores, batch["gt_option_inds"])
+            if params.get("vd_version", "1.0") == "1.0" and "gt_relevance" in batch:
+                rid = batch["round_id"].squeeze(1)
+                ndcg.observe(scores[torch.arange(scores.size(0)), rid - 1, :], batch["gt_relevance"])
+        else:
+            ranks = scores_to_ranks(scores).squeeze(1)
+            for i in range(scores.shape[0]):
+                ranks_json.append({"image_id": batch["image_id"][i].item(), "round_id": int(batch["round_id"][i].item()),
+                                   "ranks": [r.item() for r in ranks[i][:]]})
+    metrics = {}
+    if mode == "vd_eval_val":
+        metrics.update(sparse.retrieve(reset=True))
+        metrics.update(ndcg.retrieve(reset=True))
+    return ranks_json, metrics

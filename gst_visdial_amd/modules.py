@@ -337,6 +337,13 @@ class EncoderDecoderModel(nn.Module):
             object.__setattr__(self.encoder, "_standalone_engine", self._engine)
         return self._engine
 
+    def score_candidates(self, enc_image_features, enc_image_spatials, enc_image_mask, enc_input_ids, enc_segments,
+                         enc_attention_mask, dec_input_ids, dec_attention_mask, num_options):
+        """Generative ranking scores of evaluate_gen.py:45-106 with one encoder pass per dialog round (see
+        Engine.score_candidates).  Encoder tensors: one row per round; decoder tensors: num_options rows per round."""
+        return self.engine.score_candidates(enc_image_features, enc_image_spatials, enc_image_mask, enc_input_ids,
+                                            enc_segments, enc_attention_mask, dec_input_ids, dec_attention_mask, num_options)
+
     def forward(self, enc_image_features=None, enc_image_spatials=None, enc_image_mask=None, enc_image_target=None,
                 enc_image_label=None, enc_next_sentence_labels=None, enc_input_ids=None, enc_segments=None,
                 enc_sep_indices=None, enc_mlm_labels=None, enc_attention_mask=None, dec_input_ids=None,

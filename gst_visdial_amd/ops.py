@@ -356,7 +356,7 @@ def locgrad(dh, loc, M, H, dw_loc, accumulate):
 
 
 def attn_desc(Q, K, V, O, LSE, key_mask, B, nh, Lq, Lk, d, *, causal=False, mask_neg=-10000.0, scale=None, drop_p=0.0,
-              site=0, rng=None, ldq=None, ldk=None, ldv=None, ldo=None):
+              site=0, rng=None, ldq=None, ldk=None, ldv=None, ldo=None, kv_group=1):
     a = L.AttnDesc()
     a.Q, a.K, a.V, a.O, a.LSE, a.key_mask = _p(Q), _p(K), _p(V), _p(O), _p(LSE), _p(key_mask)
     a.ldq = Q.stride(-2) if ldq is None else ldq
@@ -368,6 +368,7 @@ def attn_desc(Q, K, V, O, LSE, key_mask, B, nh, Lq, Lk, d, *, causal=False, mask
     a.scale = (1.0 / (d ** 0.5)) if scale is None else scale
     a.dropout_p, a.site = drop_p, site
     a.rng = rng.ptr() if (rng is not None and drop_p > 0) else None
+    a.kv_group = kv_group
     return a
 
 

@@ -170,6 +170,10 @@ typedef struct {
   const void* dO; int64_t lddo;
   void *dQ, *dK, *dV; int64_t lddq, lddk, lddv;
   float* delta;                      /* [B, nh, Lq] fp32 scratch: rowsum(dO * O) */
+  int32_t kv_group;                  /* forward only: K, V and key_mask are shared by kv_group consecutive batch rows
+                                        (their batch index is b / kv_group); 0 or 1 = one K/V per row.  Used to score the
+                                        100 answer candidates of a dialog round against ONE encoder pass (evaluate_gen.py:45-92
+                                        re-encodes the identical context 100 times). */
 } gstvd_attn_t;
 int gstvd_attn_fwd(const gstvd_attn_t* a, gstvd_stream_t s);
 int gstvd_attn_bwd(const gstvd_attn_t* a, gstvd_stream_t s);  /* dQ (+delta) then dK,dV */

@@ -154,3 +154,17 @@ def test_product_refuses_cpu():
               enc_image_mask=g["in::enc_image_mask"], enc_input_ids=g["in::enc_input_ids"], enc_segments=g["in::enc_segments"],
               enc_attention_mask=g["in::enc_attention_mask"], dec_input_ids=g["in::dec_input_ids"],
               dec_attention_mask=g["in::dec_attention_mask"], dec_labels=g["in::dec_labels"])
+
+
+def test_metrics_bit_exact(utils_golden):
+    from gst_visdial_amd import metrics as M
+    u = utils_golden
+    assert torch.equal(M.scores_to_ranks(u["scores"]), u["ranks"])
+    sp = M.SparseGTMetrics()
+    sp.observe(u["scores"], u["gt"])
+    m = sp.retrieve()
+    got = torch.tensor([m[k] for k in ("r@1", "r@5", "r@10", "mean", "mrr")], dtype=torch.float64)
+    assert (got - u["sparse"].double()).abs().max().item() < 1e-6
+    nd = M.NDCG()
+    nd.observe(u["scores"][:, 0], u["relevance"])
+    assert abs(nd.retrieve()["ndcg"] - float(u["ndcg"][0])) < 1e-6

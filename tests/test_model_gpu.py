@@ -246,3 +246,40 @@ def test_backward_pipeline_matches_plain_optimizer_step():
     for a, b in zip(l0, l1):
         assert abs(a - b) < 1e-4 * max(1.0, abs(a)), (l0, l1)
     assert maxerr(p0, p1) < 1e-5
+
+
+def test_score_candidates_equals_per_row_reference_path():
+    """Encode-once candidate scoring == the reference's way (every candidate row through encoder+decoder, then
+    evaluate_gen.py:94-106 on the logits), and the metrics it feeds."""
+    s = sc()
+    model, params, cfg = s.build_tiny_model("fp32", DEV, mode="vd_eval_val")
+    model.eval()
+    g = load_npz("tiny_train.npz")
+    E, G = 3, 4
+    gen = torch.Generator().manual_seed(21)
+    U = g["in::eval_dec_input_ids"].shape[1]
+    dec = torch.zeros(E * G, U, dtype=torch.long)
+    for r in range(E * G):
+        n = int(torch.randint(2, U - 2, (1,), generator=gen))
+        dec[r, 0] = 101
+        dec[r, 1:1 + n] = torch.randint(104, 320, (n,), generator=gen)
+        dec[r, 1 + n] = 102
+    dmask = (torch.arange(U)[None] < ((dec != 0).sum(1, keepdim=True))).float()
+    b = {k[4:]: v.to(DEV) for k, v in g.items() if k.startswith("in::")}
+    with torch.no_grad():
+        fast = model.score_candidates(b["enc_image_features"], b["enc_image_spatials"], b["enc_image_mask"], b["enc_input_ids"],
+                                      b["enc_segments"], b["enc_attention_mask"], dec.to(DEV), dmask.to(DEV), G)
+        rep = lambda t: t.repeat_interleave(G, dim=0)
+        ids_in = dec.clone().to(DEV)
+        _, logits = model(enc_image_features=rep(b["enc_image_features"]), enc_image_spatials=rep(b["enc_image_spatials"]),
+                          enc_image_mask=rep(b["enc_image_mask"]), enc_input_ids=rep(b["enc_input_ids"]),
+                          enc_segments=rep(b["enc_segments"]), enc_attention_mask=rep(b["enc_attention_mask"]),
+                          dec_input_ids=ids_in, dec_attention_mask=dmask.to(DEV), dec_labels=None)
+        lp = torch.log_softmax(logits.float(), -1)
+        tgt = dec.new_zeros(dec.shape)
+        tgt[:, :-1] = dec[:, 1:]
+        tgt = tgt.to(DEV)
+        slow = (torch.gather(lp, -1, tgt[..., None]).squeeze(-1) * (tgt != 0).float()).sum(-1)
+    assert maxerr(fast, slow) < 2e-4
+    from gst_visdial_amd.metrics import scores_to_ranks
+    assert torch.equal(scores_to_ranks(fast.view(1, E, G).cpu()), scores_to_ranks(slow.view(1, E, G).cpu()))
