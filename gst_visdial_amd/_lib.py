@@ -35,7 +35,7 @@ class LnDesc(C.Structure):
                 ("p_pre", _f32), ("p_post", _f32), ("site_pre", _u32), ("site_post", _u32), ("rng", _vp),
                 ("ids", _vp), ("segs", _vp), ("T", _i64), ("type_vocab", _i32),
                 ("word", _vp), ("pos", _vp), ("tt", _vp), ("tt_ext", _vp),
-                ("loc", _vp), ("w_loc", _vp), ("b_loc", _vp)]
+                ("loc", _vp), ("w_loc", _vp), ("b_loc", _vp), ("pos_offset", _i64)]
 
 
 class LnBwdDesc(C.Structure):
@@ -50,7 +50,8 @@ class AttnDesc(C.Structure):
                 ("B", _i32), ("nh", _i32), ("Lq", _i32), ("Lk", _i32), ("d", _i32), ("causal", _i32), ("dtype", _i32),
                 ("mask_neg", _f32), ("scale", _f32), ("dropout_p", _f32), ("site", _u32), ("rng", _vp),
                 ("dO", _vp), ("lddo", _i64), ("dQ", _vp), ("dK", _vp), ("dV", _vp),
-                ("lddq", _i64), ("lddk", _i64), ("lddv", _i64), ("delta", _vp), ("kv_group", _i32)]
+                ("lddq", _i64), ("lddk", _i64), ("lddv", _i64), ("delta", _vp), ("kv_group", _i32),
+                ("q_bstride", _i32), ("kv_bstride", _i32)]
 
 
 class ColsumEntry(C.Structure):

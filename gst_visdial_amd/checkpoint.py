@@ -1,0 +1,53 @@
+"""Checkpoint save / resume in the reference's on-disk layout (train_gen.py:252-290, 345-357).
+
+A checkpoint is `torch.save({'model_state_dict', 'scheduler_state_dict', 'optimizer_state_dict', 'iter_id'})`; the model
+part is `EncoderDecoderModel.state_dict()` with the reference's 861 keys, so files written by the reference load
+here and files written here load there (eval / generate only read 'model_state_dict').  The optimizer part holds the
+flat AdamW moments of `FusedAdamW` (the reference's per-tensor state is not interchangeable: its optimizer is built
+before the embedding aliasing and carries orphaned parameters).
+"""
+import torch
+
+
+def save_checkpoint(path, model, optimizer=None, iter_id=0):
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ck = {"model_state_dict": sd, "iter_id": int(iter_id), "scheduler_state_dict": {}, "optimizer_state_dict": {}}
+    if optimizer is not None:
+        st = optimizer.state_dict()
+        ck["optimizer_state_dict"] = {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in st.items()}
+        ck["scheduler_state_dict"] = {"last_epoch": optimizer.sched_step, "warmup_steps": optimizer.warmup_steps,
+                                      "t_total": optimizer.t_total, "min_lr": optimizer.min_lr}
+    torch.save(ck, path)
+
+
+def load_checkpoint(path, model, optimizer=None, cont=True, map_location="cpu"):
+    """cont=True : train_gen.py:254-276 (`-continue`): key-intersected load of the whole model (+ optimizer when given);
+    cont=False: train_gen.py:278-289: only the ENCODER's keys are taken (how checkpoints/basemodel is ingested).
+    Returns iter_id (0 when absent)."""
+    ck = torch.load(path, map_location=map_location)
+    sd = ck["model_state_dict"] if "model_state_dict" in ck else ck
+    if cont:
+        own = model.state_dict()
+        own.update({k: v for k, v in sd.items() if k in own})
+        model.load_state_dict(own)
+        if optimizer is not None and ck.get("optimizer_state_dict"):
+            st = ck["optimizer_state_dict"]
+            if "m" in st:
+                optimizer.load_state_dict(st)
+            sch = ck.get("scheduler_state_dict") or {}
+            if "last_epoch" in sch:
+                optimizer.sched_step = int(sch["last_epoch"])
+        return int(ck.get("iter_id", 0)) if isinstance(ck, dict) else 0
+    enc = model.encoder
+    own = enc.state_dict()
+    # reference keys are relative to dialog_encoder (no 'encoder.' prefix) in VisDial-BERT base models, or carry it
+    take = {}
+    for k, v in sd.items():
+        kk = k[len("encoder."):] if k.startswith("encoder.") else k
+        if kk in own:
+            take[kk] = v
+    if not take:
+        raise RuntimeError("no encoder keys found in %s" % path)
+    own.update(take)
+    enc.load_state_dict(own)
+    return 0

@@ -165,9 +165,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(gstvd_attn_t a) {
   const int q = blockIdx.x * 64 + wave * 16 + li;
   const bool qv = q < a.Lq;
   const int bk = a.kv_group > 1 ? b / a.kv_group : b;       // batch row of the (possibly shared) keys / values
-  const T* Qb = (const T*)a.Q + (int64_t)b * a.Lq * a.ldq + h * D;
-  const T* Kb = (const T*)a.K + (int64_t)bk * a.Lk * a.ldk + h * D;
-  const T* Vb = (const T*)a.V + (int64_t)bk * a.Lk * a.ldv + h * D;
+  const int64_t qbs = a.q_bstride > 0 ? a.q_bstride : a.Lq, kbs = a.kv_bstride > 0 ? a.kv_bstride : a.Lk;
+  const T* Qb = (const T*)a.Q + (int64_t)b * qbs * a.ldq + h * D;
+  const T* Kb = (const T*)a.K + (int64_t)bk * kbs * a.ldk + h * D;
+  const T* Vb = (const T*)a.V + (int64_t)bk * kbs * a.ldv + h * D;
   RowFrag<T, D> qf;
   qf.load(Qb + (int64_t)q * a.ldq, qv, g);
   const DropKey dk = make_drop(a.dropout_p, a.site, a.rng);
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(gstvd_attn_t a) {
   l_tot += __shfl_xor(l_tot, 32, 64);
   const float inv = 1.f / l_tot;
   if (qv) {
-    T* Op = (T*)a.O + ((int64_t)b * a.Lq + q) * a.ldo + h * D;
+    T* Op = (T*)a.O + ((int64_t)b * qbs + q) * a.ldo + h * D;
 #pragma unroll
     for (int i = 0; i < D / 16; ++i) st4(Op + i * 16 + 4 * g, accO[i] * inv);
     if (g == 0 && a.LSE) a.LSE[((int64_t)b * a.nh + h) * a.Lq + q] = m_run + __logf(l_tot);
@@ -396,7 +397,7 @@ static int attn_check(const gstvd_attn_t* a, bool bwd) {
   if ((a->ldq % ve) || (a->ldk % ve) || (a->ldv % ve) || (a->ldo % 4)) return GSTVD_E_ALIGN;
   if (((uintptr_t)a->Q | (uintptr_t)a->K | (uintptr_t)a->V | (uintptr_t)a->O) & 15) return GSTVD_E_ALIGN;
   if (bwd) {
-    if (a->kv_group > 1) return GSTVD_E_UNSUPPORTED;
+    if (a->kv_group > 1 || a->q_bstride > 0 || a->kv_bstride > 0) return GSTVD_E_UNSUPPORTED;
     if (!a->dO || !a->dQ || !a->dK || !a->dV || !a->LSE || !a->delta) return GSTVD_E_NULL;
     if ((a->lddo % ve) || (a->lddq % 4) || (a->lddk % 4) || (a->lddv % 4)) return GSTVD_E_ALIGN;
   }

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(gstvd_ln_t f) {
   const DropKey dpost = make_drop(f.p_post, f.site_post, f.rng);
   int64_t id = 0, tpos = 0, seg = 0;
   float locrow[5] = {0, 0, 0, 0, 0};
-  if (MODE == GSTVD_LN_EMBED) { id = f.ids[row]; tpos = row % f.T; seg = f.segs ? f.segs[row] : 0; }
+  if (MODE == GSTVD_LN_EMBED) { id = f.ids[row]; tpos = row % f.T + f.pos_offset; seg = f.segs ? f.segs[row] : 0; }
   if (MODE == GSTVD_LN_IMAGE) {
 #pragma unroll
     for (int j = 0; j < 5; ++j) locrow[j] = f.loc[row * 5 + j];
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnP p) {
     float locrow[5] = {0, 0, 0, 0, 0};
     float mean = 0.f;
     if (rv[j]) {
-      if (MODE == GSTVD_LN_EMBED) { id[j] = f.ids[row]; tpos[j] = row % f.T; seg[j] = f.segs ? f.segs[row] : 0; }
+      if (MODE == GSTVD_LN_EMBED) { id[j] = f.ids[row]; tpos[j] = row % f.T + f.pos_offset; seg[j] = f.segs ? f.segs[row] : 0; }
       if (MODE == GSTVD_LN_IMAGE) {
 #pragma unroll
         for (int q = 0; q < 5; ++q) locrow[q] = f.loc[row * 5 + q];

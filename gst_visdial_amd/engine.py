@@ -473,14 +473,15 @@ class Engine(object):
         self._colsums(partial, nblk, H, [g, b, bias_name])
         x.bias_done = bias_name is not None
 
-    def embed(self, prefix, ids, segs, Bn, T, cfg):
+    def embed(self, prefix, ids, segs, Bn, T, cfg, pos_offset=0):
         M, H = Bn * T, cfg.hidden_size
         y = self.act(M, H)
         kw = dict(mode=LN_EMBED, dtype=ops.dt(y.t), M=M, H=H, gamma=self.Pv[prefix + ".ln.w"], beta=self.Pv[prefix + ".ln.b"],
                   mean=self.vec(M), rstd=self.vec(M), eps=1e-12, y=y.t, ids=ids, segs=segs, T=T,
                   type_vocab=cfg.type_vocab_size, word=self.Pv[prefix + ".word"], pos=self.Pv[prefix + ".pos"],
                   tt=self.Pv[prefix + ".tt"], tt_ext=self.Pv[prefix + ".tte"],
-                  p_post=cfg.hidden_dropout_prob if self.train else 0.0, site_post=self.site(), rng=self.rng)
+                  p_post=cfg.hidden_dropout_prob if self.train else 0.0, site_post=self.site(), rng=self.rng,
+                  pos_offset=pos_offset)
         ops.ln_fwd(**kw)
         self.push(lambda: self._embed_bwd(kw, prefix, y, M, H))
         return y
@@ -524,14 +525,14 @@ class Engine(object):
         gw, acc = self.grad_slot("vemb.loc.w")
         ops.locgrad(x.g, loc, M, H, gw, acc)
 
-    def attn(self, q, k, v, Bn, nh, Lq, Lk, d, key_mask, causal, neg, p, kv_group=1):
+    def attn(self, q, k, v, Bn, nh, Lq, Lk, d, key_mask, causal, neg, p, kv_group=1, kv_bstride=0):
         (qa, qc), (ka, kc), (va, vc) = q, k, v
         Hh = nh * d
         o = self.act(Bn * Lq, Hh)
         lse = self.vec(Bn * nh * Lq)
         a = ops.attn_desc(qa.t[:, qc:qc + Hh], ka.t[:, kc:kc + Hh], va.t[:, vc:vc + Hh], o.t, lse, key_mask, Bn, nh, Lq, Lk, d,
                           causal=causal, mask_neg=neg, drop_p=p if self.train else 0.0, site=self.site(), rng=self.rng,
-                          kv_group=kv_group)
+                          kv_group=kv_group, kv_bstride=kv_bstride)
         ops.attn_fwd(a)
         self.push(lambda: self._attn_bwd(a, q, k, v, o, Bn, nh, Lq, Hh))
         return o
@@ -836,30 +837,58 @@ class Engine(object):
     @torch.no_grad()
     def sample(self, feats, loc, img_mask, ids, segs, att_mask, dec_ids, temperature=1.0, top_k=0, top_p=0.0,
                ngram_blocking_size=0, max_seq_len=18, **_):
-        """models/visual_dialog_model.py:74-120: 18 steps of full-prefix decoding with temperature, n-gram blocking
-        and top-k/top-p filtering, multinomial draw, [PAD] after the first [SEP].  The encoder and the cross K/V
-        projection run once; token-id work (filters, n-gram ban, EOS fill) is integer-exact host/torch plumbing."""
+        """models/visual_dialog_model.py:74-120: 18 sampling steps (temperature, n-gram blocking, top-k / top-p, multinomial
+        draw, [PAD] after the first [SEP]).  The reference re-runs the whole decoder on the growing prefix and re-projects
+        the cross-attention K/V of all 37+T encoder states in all 12 layers at every step (use_cache=False); here the
+        encoder, VLFusion and the cross K/V projection run once, and each step feeds ONE token per row through the stack,
+        appending its self-attention K/V to a [B, Umax, H] cache per layer.  Same arithmetic, O(U) instead of O(U^2).
+        Token-id work (filters, n-gram ban, EOS fill) is integer-exact torch / host plumbing (decoding.py)."""
         from . import decoding
         self._begin(ids.device, False)
         self.train = False
         dc = self.dec_cfg
-        start_ids = dec_ids
-        I = self._inputs(feats, loc, img_mask, ids, segs, att_mask, start_ids, None)
+        I = self._inputs(feats, loc, img_mask, ids, segs, att_mask, dec_ids, None)
         xt, xv = self.encoder(I)
         enc = self.fusion(xt, xv, I)
-        Bn, V = I["B"], dc.vocab_size
-        hist = ids * (segs == 0).long()
-        cur = start_ids
-        seq = []
-        L, Hd = dc.num_hidden_layers, dc.hidden_size
-        kv = self.lin(enc, "dec.ckv.w", "dec.ckv.b", 2 * L * Hd, Hd)      # cross K/V of all layers, once
+        Bn, V, Vp = I["B"], dc.vocab_size, self.flat.Vp
+        L, H, nh = dc.num_hidden_layers, dc.hidden_size, dc.num_attention_heads
+        d, S, eps = H // nh, I["R"] + I["T"], dc.layer_norm_eps
+        kv = self.lin(enc, "dec.ckv.w", "dec.ckv.b", 2 * L * H, H)      # cross K/V of all layers, once
+        L0 = dec_ids.shape[1]
+        Umax = L0 + max_seq_len
+        Kc = [Act(self.buf(Bn * Umax, H), Bn * Umax, H) for _ in range(L)]
+        Vc = [Act(self.buf(Bn * Umax, H), Bn * Umax, H) for _ in range(L)]
+        prefix = "emb" if self.flat.dec_emb is self.flat.enc_emb else "demb"
         mark_ci, mark_off = self.arena.ci, self.arena.off
-        for _ in range(max_seq_len):
+
+        def one_token(tok, t):
+            """logits [B, V] for the token at position t (its K/V are appended to the caches)."""
             self.arena.ci, self.arena.off = mark_ci, mark_off
-            I["U"], I["dec_ids"], I["dmask"] = cur.shape[1], cur.contiguous().view(-1), None
-            _, logits = self.decoder(enc, I, kv)
-            U = cur.shape[1]
-            last = logits.t.view(Bn, U, self.flat.Vp)[:, -1, :V].float() / temperature
+            y = self.embed(prefix, tok.contiguous(), None, Bn, 1, dc, pos_offset=t)
+            for i in range(L):
+                p = "d%d" % i
+                qkv = self.lin(y, p + ".qkv.w", p + ".qkv.b", 3 * H, H)
+                Kc[i].t.view(Bn, Umax, H)[:, t].copy_(qkv.t[:, H:2 * H])
+                Vc[i].t.view(Bn, Umax, H)[:, t].copy_(qkv.t[:, 2 * H:])
+                ctx = self.attn((qkv, 0), (Kc[i], 0), (Vc[i], 0), Bn, nh, 1, t + 1, d, None, False, -10000.0, 0.0, kv_bstride=Umax)
+                ao = self.lin(ctx, p + ".ao.w", p + ".ao.b", H, H)
+                y1 = self.ln(ao, y, p + ".ln1.w", p + ".ln1.b", H, 0.0, None, eps)
+                q = self.lin(y1, p + ".cq.w", p + ".cq.b", H, H)
+                ctx = self.attn((q, 0), (kv, 2 * i * H), (kv, (2 * i + 1) * H), Bn, nh, 1, S, d, I["emask"], False, -1e9, 0.0)
+                co = self.lin(ctx, p + ".co.w", p + ".co.b", H, H)
+                y2 = self.ln(co, y1, p + ".ln2.w", p + ".ln2.b", H, 0.0, None, eps)
+                a = self.lin(y2, p + ".fi.w", p + ".fi.b", dc.intermediate_size, H, gelu=True)
+                fo = self.lin(a, p + ".fo.w", p + ".fo.b", H, dc.intermediate_size)
+                y = self.ln(fo, y2, p + ".ln3.w", p + ".ln3.b", H, 0.0, None, eps)
+            return self.lin(y, "lm.w", "lm.b", Vp, H).t[:, :V].float()
+
+        hist = ids * (segs == 0).long()
+        cur, seq = dec_ids, []
+        for t in range(Umax - 1):
+            logits = one_token(cur[:, t], t)
+            if t < L0 - 1:
+                continue                                   # still consuming the given prefix
+            last = logits / temperature
             last = decoding.batch_ngram_blocking(last, hist, cur, ngram_size=ngram_blocking_size)
             last = decoding.batch_top_k_top_p_sampling(last, top_k=top_k, top_p=top_p)
             nxt = torch.multinomial(torch.softmax(last, dim=-1), 1)

@@ -203,7 +203,7 @@ class GemmGroup(object):
 
 def _ln_desc(mode, dtype, M, H, gamma, beta, mean, rstd, eps, x=None, res=None, y=None, p_pre=0.0, p_post=0.0,
              site_pre=0, site_post=0, rng=None, ids=None, segs=None, T=0, type_vocab=2, word=None, pos=None, tt=None,
-             tt_ext=None, loc=None, w_loc=None, b_loc=None):
+             tt_ext=None, loc=None, w_loc=None, b_loc=None, pos_offset=0):
     d = L.LnDesc()
     d.mode, d.dtype, d.M, d.H = mode, dtype, M, H
     d.x, d.ldx = _p(x), (x.stride(-2) if x is not None else 0)
@@ -216,6 +216,7 @@ def _ln_desc(mode, dtype, M, H, gamma, beta, mean, rstd, eps, x=None, res=None, 
     d.ids, d.segs, d.T, d.type_vocab = _p(ids), _p(segs), T, type_vocab
     d.word, d.pos, d.tt, d.tt_ext = _p(word), _p(pos), _p(tt), _p(tt_ext)
     d.loc, d.w_loc, d.b_loc = _p(loc), _p(w_loc), _p(b_loc)
+    d.pos_offset = pos_offset
     return d
 
 
@@ -356,7 +357,7 @@ def locgrad(dh, loc, M, H, dw_loc, accumulate):
 
 
 def attn_desc(Q, K, V, O, LSE, key_mask, B, nh, Lq, Lk, d, *, causal=False, mask_neg=-10000.0, scale=None, drop_p=0.0,
-              site=0, rng=None, ldq=None, ldk=None, ldv=None, ldo=None, kv_group=1):
+              site=0, rng=None, ldq=None, ldk=None, ldv=None, ldo=None, kv_group=1, q_bstride=0, kv_bstride=0):
     a = L.AttnDesc()
     a.Q, a.K, a.V, a.O, a.LSE, a.key_mask = _p(Q), _p(K), _p(V), _p(O), _p(LSE), _p(key_mask)
     a.ldq = Q.stride(-2) if ldq is None else ldq
@@ -368,7 +369,7 @@ def attn_desc(Q, K, V, O, LSE, key_mask, B, nh, Lq, Lk, d, *, causal=False, mask
     a.scale = (1.0 / (d ** 0.5)) if scale is None else scale
     a.dropout_p, a.site = drop_p, site
     a.rng = rng.ptr() if (rng is not None and drop_p > 0) else None
-    a.kv_group = kv_group
+    a.kv_group, a.q_bstride, a.kv_bstride = kv_group, q_bstride, kv_bstride
     return a
 
 

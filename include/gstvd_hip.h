@@ -97,10 +97,11 @@ typedef struct {
   float p_pre, p_post; uint32_t site_pre, site_post; const uint64_t* rng;
   /* EMBED */
   const int64_t* ids; const int64_t* segs; /* [M]; segs may be NULL (=0) */
-  int64_t T; int32_t type_vocab;           /* position = row % T */
+  int64_t T; int32_t type_vocab;           /* position = row % T + pos_offset */
   const float* word; const float* pos; const float* tt; const float* tt_ext; /* fp32 tables, row stride H */
   /* IMAGE */
   const float* loc; const float* w_loc; const float* b_loc; /* loc [M,5] fp32, w_loc [H,5], b_loc [H] */
+  int64_t pos_offset;                      /* EMBED: added to the position (KV-cached decode feeds one token per row) */
 } gstvd_ln_t;
 int gstvd_ln_fwd(const gstvd_ln_t* p, gstvd_stream_t s);
 
@@ -174,6 +175,8 @@ typedef struct {
                                         (their batch index is b / kv_group); 0 or 1 = one K/V per row.  Used to score the
                                         100 answer candidates of a dialog round against ONE encoder pass (evaluate_gen.py:45-92
                                         re-encodes the identical context 100 times). */
+  int32_t q_bstride, kv_bstride;     /* forward only: rows between consecutive batch elements of Q/O resp. K/V (0 = Lq / Lk).
+                                        Lets one decode step (Lq = 1) read a [B, Umax, H] K/V cache of which Lk rows are filled. */
 } gstvd_attn_t;
 int gstvd_attn_fwd(const gstvd_attn_t* a, gstvd_stream_t s);
 int gstvd_attn_bwd(const gstvd_attn_t* a, gstvd_stream_t s);  /* dQ (+delta) then dK,dV */

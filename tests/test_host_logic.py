@@ -168,3 +168,31 @@ def test_metrics_bit_exact(utils_golden):
     nd = M.NDCG()
     nd.observe(u["scores"][:, 0], u["relevance"])
     assert abs(nd.retrieve()["ndcg"] - float(u["ndcg"][0])) < 1e-6
+
+
+def test_checkpoint_round_trip_reference_layout(tiny_state, tmp_path):
+    from gst_visdial_amd.checkpoint import save_checkpoint, load_checkpoint
+    model, enc, dec = _tiny_model()
+    dec.decoder.bert.embeddings = enc.bert_pretrained.bert.embeddings
+    model.load_state_dict(tiny_state, strict=True)
+    p = str(tmp_path / "vd_train_0_1.ckpt")
+    save_checkpoint(p, model, None, iter_id=77)
+    ck = torch.load(p)
+    assert set(ck.keys()) == {"model_state_dict", "scheduler_state_dict", "optimizer_state_dict", "iter_id"}      # train_gen.py:346-351
+    assert set(ck["model_state_dict"].keys()) == set(tiny_state.keys())
+    # a checkpoint written in the reference's format (here: the golden state dict) resumes with -continue semantics
+    ref = str(tmp_path / "ref.ckpt")
+    torch.save({"model_state_dict": tiny_state, "iter_id": 5, "optimizer_state_dict": {}, "scheduler_state_dict": {}}, ref)
+    m2, e2, d2 = _tiny_model()
+    d2.decoder.bert.embeddings = e2.bert_pretrained.bert.embeddings
+    assert load_checkpoint(ref, m2, cont=True) == 5
+    for k, v in m2.state_dict().items():
+        assert torch.equal(v, tiny_state[k]), k
+    # encoder-only ingestion (train_gen.py:278-289): decoder / fusion keep their init
+    m3, e3, d3 = _tiny_model()
+    d3.decoder.bert.embeddings = e3.bert_pretrained.bert.embeddings
+    before = m3.vlfusion.fc_l.weight.clone()
+    load_checkpoint(ref, m3, cont=False)
+    assert torch.equal(m3.vlfusion.fc_l.weight, before)
+    assert torch.equal(m3.encoder.bert_pretrained.bert.encoder.layer[0].attention.self.query.weight,
+                       tiny_state["encoder.bert_pretrained.bert.encoder.layer.0.attention.self.query.weight"])

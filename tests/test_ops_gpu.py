@@ -402,3 +402,35 @@ def test_gemm_grouped_matches_individual_launches():
     grp.flush()
     for i, (dw, ref) in enumerate(refs):
         check("gemm_grouped_%d" % i, dw, ref, torch.bfloat16, 2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_kv_cache_strides_and_shared_kv(dtype):
+    """Forward-only descriptor extras: Lq = 1 against a partially filled [B, Umax, H] cache (kv_bstride) and K/V shared
+    by groups of batch rows (kv_group)."""
+    o = ops()
+    Bn, nh, d, Umax, Lk = 5, 4, 32, 19, 7
+    H = nh * d
+    q = rnd(Bn, H, dtype=dtype, seed=110)
+    kc, vc = rnd(Bn * Umax, H, dtype=dtype, seed=111), rnd(Bn * Umax, H, dtype=dtype, seed=112)
+    out = torch.empty(Bn, H, device=DEV, dtype=dtype)
+    lse = torch.empty(Bn, nh, 1, device=DEV)
+    a = o.attn_desc(q, kc, vc, out, lse, None, Bn, nh, 1, Lk, d, kv_bstride=Umax)
+    o.attn_fwd(a)
+    k3, v3 = kc.view(Bn, Umax, nh, d)[:, :Lk].float(), vc.view(Bn, Umax, nh, d)[:, :Lk].float()
+    ref, _ = attn_ref(q.float().view(Bn, 1, nh, d), k3, v3, torch.ones(Bn, Lk, device=DEV), False, -1e4, 1 / math.sqrt(d), None)
+    check("attn_cache", out.view(Bn, 1, nh, d), ref, dtype, 2.0)
+    # shared K/V: 6 query rows, 2 K/V rows, groups of 3
+    Bq, G, Lq, Lk2 = 6, 3, 9, 21
+    Q = rnd(Bq * Lq, H, dtype=dtype, seed=113)
+    K, V = rnd(2 * Lk2, H, dtype=dtype, seed=114), rnd(2 * Lk2, H, dtype=dtype, seed=115)
+    km = torch.ones(2, Lk2, device=DEV)
+    km[1, 15:] = 0
+    O = torch.empty(Bq * Lq, H, device=DEV, dtype=dtype)
+    lse2 = torch.empty(Bq, nh, Lq, device=DEV)
+    a = o.attn_desc(Q, K, V, O, lse2, km, Bq, nh, Lq, Lk2, d, mask_neg=-1e9, kv_group=G)
+    o.attn_fwd(a)
+    rep = lambda t: t.repeat_interleave(G, dim=0)
+    ref, _ = attn_ref(Q.float().view(Bq, Lq, nh, d), rep(K.float().view(2, Lk2, nh, d)), rep(V.float().view(2, Lk2, nh, d)),
+                      rep(km), False, -1e9, 1 / math.sqrt(d), None)
+    check("attn_shared_kv", O.view(Bq, Lq, nh, d), ref, dtype, 2.0)
