@@ -124,7 +124,8 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
-    ap.add_argument("--grad-compress", default=None, choices=[None, "bf16"])
+    ap.add_argument("--grad-compress", default="auto", choices=["auto", "none", "bf16"],
+                    help="dtype of the gradient all-reduce payload (auto: bf16 for N>1 -- halves xGMI traffic; fp32 master grads kept)")
     ap.add_argument("--breakdown-json", default=None, help="write the per-kernel breakdown here")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the whole train step as one hipGraph (auto: on for 1 GPU, off for N>1)")
@@ -139,9 +140,13 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    force_dist = bool(os.environ.get("GSTVD_FORCE_DIST"))      # exercise the RCCL path on one GPU (validation only)
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
@@ -157,7 +162,9 @@ def main():
     opt = FusedAdamW(model, lr=2e-5, warmup_steps=1500, t_total=100000)
     # gradients are finalised slice by slice on a third stream during backward: grouped wgrad GEMMs -> column
     # reductions -> (N>1) RCCL all-reduce of the slice -> fused AdamW on the slice
-    pipe = BackwardPipeline(model.engine, optimizer=opt, chunk_elems=args.chunk_melems << 20, compress=args.grad_compress)
+    compress = {"auto": "bf16" if world > 1 else None, "none": None, "bf16": "bf16"}[args.grad_compress]
+    pipe = BackwardPipeline(model.engine, optimizer=opt, chunk_elems=args.chunk_melems << 20, compress=compress,
+                            force_collective=force_dist)
 
     def step():
         loss, _ = model(**batch)
@@ -168,13 +175,13 @@ def main():
         return loss
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_dist:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
 
     eager_step = step
-    use_graph = args.graph == "on" or (args.graph == "auto" and world == 1)
+    use_graph = args.graph == "on" or (args.graph == "auto" and world == 1 and not force_dist)
     for _ in range(max(args.warmup, 2) if use_graph else args.warmup):
         loss = step()
     if use_graph:
@@ -258,10 +265,14 @@ def main():
                "roofline": roofline, "cpu_baseline": cpu}
         if breakdown is not None:
             out["kernel_breakdown_ms"] = {k: v["ms"] for k, v in list(breakdown.items())[:12]}
-        print(json.dumps(out))
-    if world > 1:
+        out["config"]["grad_allreduce_dtype"] = (compress or "fp32") if world > 1 else None
+    if world > 1 or force_dist:
         import torch.distributed as dist
-        dist.destroy_process_group()
+        dist.barrier()
+        dist.destroy_process_group()          # RCCL prints its banner here; the JSON line must come last
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -18,11 +18,12 @@ import torch.distributed as dist
 
 
 class BackwardPipeline(object):
-    def __init__(self, engine, optimizer=None, group=None, chunk_elems=40 << 20, compress=None):
+    def __init__(self, engine, optimizer=None, group=None, chunk_elems=40 << 20, compress=None, force_collective=False):
         self.engine, self.opt, self.group = engine, optimizer, group
         self.chunk = chunk_elems
         self.compress = compress
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.collective = self.world > 1 or (force_collective and dist.is_initialized())
         self.hi = None
         self.slices = []
         if optimizer is not None:
@@ -44,7 +45,7 @@ class BackwardPipeline(object):
         """Runs on the auxiliary stream, after the slice's weight-gradient GEMMs and column reductions."""
         flat = self.engine.flat
         self.slices.append((lo, hi))
-        if self.world > 1:
+        if self.collective:
             sl = flat.G[lo:hi]
             if self.compress == "bf16":
                 from . import ops
