@@ -114,6 +114,15 @@ def cpu_baseline(model, T, R, U, F, V, rows=2):
                       % (n, T, R, U, threads, dt)}
 
 
+def _flush_c_stdio():
+    """RCCL (NCCL_DEBUG=VERSION) prints through C stdio; flush it so that bench.py's JSON is the last stdout line."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -270,6 +279,7 @@ def main():
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()          # RCCL prints its banner here; the JSON line must come last
+    _flush_c_stdio()                          # ... and it sits in the C stdio buffer: push it out before our line
     if rank == 0:
         sys.stdout.flush()
         print(json.dumps(out), flush=True)

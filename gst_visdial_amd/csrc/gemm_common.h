@@ -120,3 +120,15 @@ template <typename K> static int ensure_lds(K kernel, int bytes) {
 int gemm_dma_dispatch(const GemmP& p, int64_t batch, int akm, int bkm, int out_f32, hipStream_t s);
 // gemm_dma256.hip: 256x256x32 tile for problems whose grid still fills the chip
 int gemm_dma256_dispatch(const GemmP& p, int64_t batch, int akm, int bkm, int out_f32, hipStream_t s);
+
+// LDS-DMA issue in inline asm.  The compiler's waitcnt pass treats a *builtin* global_load_lds as a pending LDS write and
+// puts `s_waitcnt vmcnt(0)` in front of every ds_read_b64_tr_b16 that follows (it cannot see that the ring slot being
+// read is not the one being filled) -- which serialises the ring for k-major operands.  Issued from asm the DMA is
+// invisible to that pass; ordering is ours: a counted `s_waitcnt vmcnt(N)` + s_barrier before a slot is read, and
+// `s_waitcnt vmcnt(0)` before the epilogue.  m0 (the LDS destination base) is saved/restored around the instruction.
+DEVFN void glds16_asm(const char* gsrc, unsigned lds_dst_uniform) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
+}
+DEVFN unsigned lds_addr(const char* p) { return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }

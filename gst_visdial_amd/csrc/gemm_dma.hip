@@ -20,7 +20,7 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 DEVFN void glds16(const char* src, char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
+  glds16_asm(src, __builtin_amdgcn_readfirstlane(lds_addr(lds_wave_base)));
 }
 
 // Per-thread description of the 16-byte units this thread feeds into one operand image, fixed over the K loop.

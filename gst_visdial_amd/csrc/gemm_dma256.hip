@@ -73,7 +73,7 @@ struct Dma32 {
     for (int i = 0; i < NP; ++i) {
       const bool ok = okx[i] && (kt * 32 + kofs[i] < K);
       const char* src = ok ? ptr[i] + kt * kstep : (const char*)g_zero_page256;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(img + (i * NT + wave * 64) * 16), 16, 0, 0);
+      glds16_asm(src, __builtin_amdgcn_readfirstlane(lds_addr(img + (i * NT + wave * 64) * 16)));
     }
   }
   // Pull the K-slice `kt` into this XCD's L2 ahead of time: a 4-byte LDS-DMA per unit into a per-wave scratch
@@ -128,13 +128,15 @@ DEVFN void dma_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPS) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    // PF < 0 are timing-only ablations (wrong results): -1 = no DMA inside the loop, -2 = no LDS reads / MFMA
-    if (PF != -1) {
-      ua.issue(t + NS - 1, p.K, smem + fill * STAGE, wave);
-      ub.issue(t + NS - 1, p.K, smem + fill * STAGE + A_BYTES, wave);
-    } else {
+    // PF < 0: -1 / -2 are timing-only ablations (wrong results): -1 = no DMA inside the loop, -2 = no LDS reads / MFMA;
+    // -3 / -4 are schedule experiments (correct results): the wm==1 waves issue their DMA after the MFMAs (-4: + setprio)
+    const bool late = (PF == -3 || PF == -4) && wm == 1;
+    if (PF == -1) {
       ua.issue(1 << 20, p.K, smem + fill * STAGE, wave);      // zero-page DMAs keep the vmcnt bookkeeping identical
       ub.issue(1 << 20, p.K, smem + fill * STAGE + A_BYTES, wave);
+    } else if (!late) {
+      ua.issue(t + NS - 1, p.K, smem + fill * STAGE, wave);
+      ub.issue(t + NS - 1, p.K, smem + fill * STAGE + A_BYTES, wave);
     }
     if (PF > 0) { ua.prefetch(t + NS - 1 + PF, p.K, scratch, wave); ub.prefetch(t + NS - 1 + PF, p.K, scratch, wave); }
     const char* cA = smem + slot * STAGE;
@@ -143,12 +145,18 @@ DEVFN void dma_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char
       bf16x8 fb[NI];
 #pragma unroll
       for (int j = 0; j < NI; ++j) fb[j] = frag32<BN, BKM>(cB, wn * WTN + j * 16, lane);
+      if (PF == -4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const bf16x8 fa = frag32<BM, AKM>(cA, wm * WTM + i * 16, lane);
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = mfma_bf16_k32(fb[j], fa, acc[i][j]);
       }
+      if (PF == -4) __builtin_amdgcn_s_setprio(0);
+    }
+    if (late) {
+      ua.issue(t + NS - 1, p.K, smem + fill * STAGE, wave);
+      ub.issue(t + NS - 1, p.K, smem + fill * STAGE + A_BYTES, wave);
     }
     slot = (slot + 1 == NS) ? 0 : slot + 1;
     fill = (fill + 1 == NS) ? 0 : fill + 1;
@@ -164,6 +172,108 @@ DEVFN void dma_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char
       gemm_epilogue_tile<bf16, OT>(p, dk, acc[i][j], z, m0 + wm * WTM + i * 16 + li, n0 + wn * WTN + j * 16 + 4 * g);
 }
 
+// Ping-pong schedule of the same tile: the two wave groups (wm = 0 / 1, one wave of each per SIMD) run one slot apart, so
+// in every slot one group issues 16 MFMAs from registers while the other reads its next fragments from LDS and issues its
+// share of the LDS-DMA.  Per 32-deep stage and group: L0 (A pieces, 4 B + 4 A fragments) | M0 (rows 0-3) | L1 (B pieces,
+// 4 A fragments, counted vmcnt for stage t+1) | M1 (rows 4-7); every slot ends in a workgroup barrier.
+// Ordering: a stage is read from the slot after the barrier that follows every wave's vmcnt wait for it; a ring slot is
+// refilled only after the barrier that follows the lgkmcnt(0) retiring its last fragment read.
+template <typename OT, bool AKM, bool BKM>
+DEVFN void pp_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char* smem) {
+  constexpr int BM = 256, BN = 256, WN = 4, NS = NS256, NT = 512;
+  constexpr int WTM = 128, WTN = 64, NI = 4, HI = 4;
+  constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;
+  constexpr int NPA = A_BYTES / (NT * 16), NPB = B_BYTES / (NT * 16), LPS = NPA + NPB;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int ntm = nwg / ntn;
+  const int strip = wg / (2 * ntm), sw = (ntn - strip * 2) < 2 ? (ntn - strip * 2) : 2;
+  const int within = wg - strip * 2 * ntm;
+  const int64_t m0 = (int64_t)(within / sw) * BM, n0 = (int64_t)(strip * 2 + within % sw) * BN;
+
+  Dma32<BM, AKM, NPA, NT> ua;
+  Dma32<BN, BKM, NPB, NT> ub;
+  ua.init(p.A + z * p.sA * 2, p.lda, m0, p.M, tid);
+  ub.init(p.B + z * p.sB * 2, p.ldb, n0, p.N, tid);
+
+  f32x4 acc[2 * HI][NI];
+#pragma unroll
+  for (int i = 0; i < 2 * HI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int64_t nkt = (p.K + 31) / 32;
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) {
+    ua.issue(s, p.K, smem + s * STAGE, wave);
+    ub.issue(s, p.K, smem + s * STAGE + A_BYTES, wave);
+  }
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPS) : "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();            // group 1 runs one slot behind group 0
+  __builtin_amdgcn_sched_barrier(0);
+
+  int slot = 0, fill = NS - 1;
+  for (int64_t t = 0; t < nkt; ++t) {
+    const char* cA = smem + slot * STAGE;
+    const char* cB = cA + A_BYTES;
+    bf16x8 fb[NI], fa0[HI], fa1[HI];
+    // ---- L0
+    ua.issue(t + NS - 1, p.K, smem + fill * STAGE, wave);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) fb[j] = frag32<BN, BKM>(cB, wn * WTN + j * 16, lane);
+#pragma unroll
+    for (int i = 0; i < HI; ++i) fa0[i] = frag32<BM, AKM>(cA, wm * WTM + i * 16, lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- M0
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < HI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = mfma_bf16_k32(fb[j], fa0[i], acc[i][j]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- L1
+    ub.issue(t + NS - 1, p.K, smem + fill * STAGE + A_BYTES, wave);
+#pragma unroll
+    for (int i = 0; i < HI; ++i) fa1[i] = frag32<BM, AKM>(cA, wm * WTM + (HI + i) * 16, lane);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPS) : "memory");     // own pieces of stage t+1 have landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- M1
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < HI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[HI + i][j] = mfma_bf16_k32(fb[j], fa1[i], acc[HI + i][j]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    slot = (slot + 1 == NS) ? 0 : slot + 1;
+    fill = (fill + 1 == NS) ? 0 : fill + 1;
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();            // pairs with group 1's extra barrier
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  const int g = lane >> 4, li = lane & 15;
+  const DropKey dk = make_drop((p.epi & GSTVD_EPI_DROPOUT) ? p.p : 0.f, p.site, p.rng);
+#pragma unroll
+  for (int i = 0; i < 2 * HI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+      gemm_epilogue_tile<bf16, OT>(p, dk, acc[i][j], z, m0 + wm * WTM + i * 16 + li, n0 + wn * WTN + j * 16 + 4 * g);
+}
+
 DEVFN int xcd_remap256(int bid, int nwg) {
   const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
@@ -172,7 +282,8 @@ DEVFN int xcd_remap256(int bid, int nwg) {
 template <typename OT, bool AKM, bool BKM, int PF>
 __global__ __launch_bounds__(512) void gemm_dma256_kernel(GemmP p, int ntn, int nwg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  dma_tile256<OT, AKM, BKM, PF>(p, blockIdx.y, xcd_remap256(blockIdx.x, nwg), ntn, nwg, smem);
+  if (PF == -5) pp_tile256<OT, AKM, BKM>(p, blockIdx.y, xcd_remap256(blockIdx.x, nwg), ntn, nwg, smem);
+  else dma_tile256<OT, AKM, BKM, PF>(p, blockIdx.y, xcd_remap256(blockIdx.x, nwg), ntn, nwg, smem);
 }
 
 template <typename OT, bool AKM, bool BKM, int PF>
@@ -202,11 +313,14 @@ static int launch256(const GemmP& p, int64_t batch, hipStream_t s) {
   auto k0 = gemm_dma256_kernel<OT, AKM, BKM, 0>;
   auto ka = gemm_dma256_kernel<OT, AKM, BKM, -1>;
   auto kb = gemm_dma256_kernel<OT, AKM, BKM, -2>;
-  static int attr_rc = ensure_lds(k0, LDS256) | ensure_lds(ka, LDS256) | ensure_lds(kb, LDS256);
+  auto kc = gemm_dma256_kernel<OT, AKM, BKM, -3>;
+  auto kd = gemm_dma256_kernel<OT, AKM, BKM, -4>;
+  auto ke = gemm_dma256_kernel<OT, AKM, BKM, -5>;
+  static int attr_rc = ensure_lds(k0, LDS256) | ensure_lds(ka, LDS256) | ensure_lds(kb, LDS256) | ensure_lds(kc, LDS256) | ensure_lds(kd, LDS256) | ensure_lds(ke, LDS256);
   if (attr_rc) return attr_rc;
   static const int abl = [] { const char* e = getenv("GSTVD_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
   const int ntm = (int)((p.M + 255) / 256), ntn = (int)((p.N + 255) / 256);
-  hipLaunchKernelGGL(abl == 1 ? ka : (abl == 2 ? kb : k0), dim3((unsigned)(ntm * ntn), (unsigned)batch), dim3(512), LDS256, s, p, ntn, ntm * ntn);
+  hipLaunchKernelGGL(abl == 1 ? ka : abl == 2 ? kb : abl == 3 ? kc : abl == 4 ? kd : abl == 5 ? ke : k0, dim3((unsigned)(ntm * ntn), (unsigned)batch), dim3(512), LDS256, s, p, ntn, ntm * ntn);
   GSTVD_LAUNCH_CHECK();
   return 0;
 }

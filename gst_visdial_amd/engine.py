@@ -44,27 +44,48 @@ class Act(object):
 
 
 class Arena(object):
-    """Bump allocator over large device chunks; `reset()` rewinds, so a fixed call sequence gets fixed addresses."""
+    """Bump allocator over large device chunks; `reset()` rewinds, so a fixed call sequence gets fixed addresses
+    (hipGraph friendly).  The request sequence of a step is identical from step to step, so the tensor views are
+    memoised by sequence index: steady-state allocation is a list lookup, no tensor construction."""
+
+    _ESZ = {torch.float32: 4, torch.bfloat16: 2, torch.int64: 8, torch.uint8: 1, torch.int32: 4}
 
     def __init__(self, device, chunk_bytes=1 << 28):
         self.device, self.chunk_bytes = device, chunk_bytes
         self.chunks, self.ci, self.off = [], 0, 0
-        self.high = 0
+        self.memo, self.seq = [], 0
 
     def reset(self):
-        self.ci, self.off = 0, 0
+        self.ci, self.off, self.seq = 0, 0, 0
 
-    _ESZ = {torch.float32: 4, torch.bfloat16: 2, torch.int64: 8, torch.uint8: 1, torch.int32: 4}
+    def rewind(self, mark):
+        """Back to a position returned by `mark()` (decode loops reuse the same scratch every step)."""
+        self.ci, self.off, self.seq = mark
 
-    def alloc(self, numel, dtype):
+    def mark(self):
+        return (self.ci, self.off, self.seq)
+
+    def alloc(self, numel, dtype, shape=None):
         nbytes = _round_up(numel * self._ESZ[dtype], 256)
+        i = self.seq
+        self.seq = i + 1
+        if i < len(self.memo):
+            m = self.memo[i]
+            if m[0] == numel and m[1] is dtype and m[2] == shape and m[3] == self.ci and m[4] == self.off:
+                self.ci, self.off = m[5], m[6]
+                return m[7]
+            del self.memo[i:]                 # the sequence diverged (different shapes): rebuild from here
+        ci0, off0 = self.ci, self.off
         while True:
             if self.ci >= len(self.chunks):
                 self.chunks.append(torch.empty(max(self.chunk_bytes, nbytes), dtype=torch.uint8, device=self.device))
             c = self.chunks[self.ci]
             if self.off + nbytes <= c.numel():
                 out = c[self.off:self.off + nbytes].view(dtype)[:numel]
+                if shape is not None:
+                    out = out.view(shape)
                 self.off += nbytes
+                self.memo.append((numel, dtype, shape, ci0, off0, self.ci, self.off, out))
                 return out
             self.ci, self.off = self.ci + 1, 0
 
@@ -307,7 +328,7 @@ class Engine(object):
 
     # ------------------------------------------------------------------------------------------ helpers
     def buf(self, M, N, dtype=None):
-        return self.arena.alloc(M * N, dtype or self.adt).view(M, N)
+        return self.arena.alloc(M * N, dtype or self.adt, (M, N))
 
     def vec(self, n, dtype=torch.float32):
         return self.arena.alloc(n, dtype)
@@ -692,7 +713,7 @@ class Engine(object):
         tm = att_mask if att_mask is not None else torch.ones(Bn, T, device=dev)
         vm = img_mask if img_mask is not None else torch.ones(Bn, R, device=dev)
         I["tmask"], I["vmask"] = tm.float().contiguous(), vm.float().contiguous()
-        em = self.arena.alloc(Bn * (R + T), torch.float32).view(Bn, R + T)
+        em = self.arena.alloc(Bn * (R + T), torch.float32, (Bn, R + T))
         em[:, :R].copy_(I["vmask"])
         em[:, R:].copy_(I["tmask"])
         I["emask"] = em
@@ -859,11 +880,11 @@ class Engine(object):
         Kc = [Act(self.buf(Bn * Umax, H), Bn * Umax, H) for _ in range(L)]
         Vc = [Act(self.buf(Bn * Umax, H), Bn * Umax, H) for _ in range(L)]
         prefix = "emb" if self.flat.dec_emb is self.flat.enc_emb else "demb"
-        mark_ci, mark_off = self.arena.ci, self.arena.off
+        mark = self.arena.mark()
 
         def one_token(tok, t):
             """logits [B, V] for the token at position t (its K/V are appended to the caches)."""
-            self.arena.ci, self.arena.off = mark_ci, mark_off
+            self.arena.rewind(mark)
             y = self.embed(prefix, tok.contiguous(), None, Bn, 1, dc, pos_offset=t)
             for i in range(L):
                 p = "d%d" % i
