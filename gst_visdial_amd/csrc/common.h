@@ -94,12 +94,23 @@ DEVFN f32x4 drop_factor4(const DropKey& k, uint64_t e) {
   return f;
 }
 
-// ---- exact erf GELU (vilbert_dialog.py:115-121) -------------------------------------------------
-DEVFN float gelu_f(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
-DEVFN float dgelu_f(float x) {
-  float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-  float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+// ---- erf GELU (vilbert_dialog.py:115-121): value and derivative from one exp ---------------------
+// gelu(x) = x*Phi(x), gelu'(x) = Phi(x) + x*phi(x).  FAST (bf16 operands) evaluates erf with Abramowitz-Stegun 7.1.26
+// (|err| <= 1.5e-7, far below a bf16 ulp) sharing exp(-x^2/2) with phi; the fp32 path keeps libm's erff.
+template <bool FAST> DEVFN void gelu_both(float x, float& g, float& dg) {
+  const float e = __expf(-0.5f * x * x);
+  float erfv;
+  if (FAST) {
+    const float az = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * az);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    erfv = copysignf(1.0f - poly * e, x);
+  } else {
+    erfv = erff(x * 0.70710678118654752440f);
+  }
+  const float cdf = 0.5f + 0.5f * erfv;
+  g = x * cdf;
+  dg = cdf + x * (0.39894228040143267794f * e);
 }
 
 // ---- MFMA wrappers: D(16x16) += A(16xK) * B(Kx16), fp32 accumulate ----------------------------

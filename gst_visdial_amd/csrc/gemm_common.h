@@ -99,13 +99,14 @@ DEVFN void gemm_epilogue_tile(const GemmP& p, const DropKey& dk, f32x4 acc, int6
   if (p.epi & GSTVD_EPI_BIAS) v += *(const f32x4*)(p.bias + n);
   if (p.epi & GSTVD_EPI_ADD) v += ld4((const OT*)p.addend + z * p.sAdd + m * p.ldadd + n);
   if (p.epi & GSTVD_EPI_GELU) {
-    st4((T*)p.aux + z * p.sAux + m * p.ldaux + n, v);
-    v = (f32x4){gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])};
+    // aux keeps gelu'(pre-activation): the backward epilogue is then a plain multiply (no erf / exp there)
+    constexpr bool FAST = sizeof(T) == 2;
+    f32x4 d;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { float g_, d_; gelu_both<FAST>(v[e], g_, d_); v[e] = g_; d[e] = d_; }
+    st4((T*)p.aux + z * p.sAux + m * p.ldaux + n, d);
   }
-  if (p.epi & GSTVD_EPI_DGELU) {
-    f32x4 u = ld4((const T*)p.aux + z * p.sAux + m * p.ldaux + n);
-    v *= (f32x4){dgelu_f(u[0]), dgelu_f(u[1]), dgelu_f(u[2]), dgelu_f(u[3])};
-  }
+  if (p.epi & GSTVD_EPI_DGELU) v *= ld4((const T*)p.aux + z * p.sAux + m * p.ldaux + n);
   if (dk.on) v *= drop_factor4(dk, (uint64_t)((z * p.M + m) * p.N + n));
   st4(C + m * p.ldc + n, v);
 }

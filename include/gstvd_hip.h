@@ -45,8 +45,8 @@ const char* gstvd_build_arch(void);     /* "gfx950" */
  * Epilogue flags (bitmask), applied in this order:
  *   GSTVD_EPI_BIAS      += bias[n]                       (bias is always fp32)
  *   GSTVD_EPI_ADD       += addend[m,n]                   (dtype_out; residual / grad accumulate)
- *   GSTVD_EPI_GELU      aux[m,n] = v (pre-activation, dtype_in); v = gelu_erf(v)   (vilbert_dialog.py:115-121)
- *   GSTVD_EPI_DGELU     v *= gelu_erf'(aux[m,n])
+ *   GSTVD_EPI_GELU      aux[m,n] = gelu_erf'(v) (dtype_in); v = gelu_erf(v)   (vilbert_dialog.py:115-121)
+ *   GSTVD_EPI_DGELU     v *= aux[m,n]   (aux as written by the forward GELU epilogue)
  *   GSTVD_EPI_DROPOUT   v *= keep(site, (z*M+m)*N+n) / (1-p)      (VLFusion dropout, visual_dialog_model.py:133)
  * Constraints: N % 4 == 0; row-major operands need K % (16/sizeof(T)) == 0 and 16-byte aligned rows;
  * k-major operands need their M (resp. N) extent % (16/sizeof(T)) == 0.  M and the k extent of

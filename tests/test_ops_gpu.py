@@ -92,16 +92,16 @@ def test_gemm_gelu_epilogues(dtype):
     u = torch.empty(M, N, device=DEV, dtype=dtype)
     a = torch.empty(M, N, device=DEV, dtype=dtype)
     o.gemm(x, w, a, M, N, K, bias=b, aux=u, epi=o.EPI_GELU)
-    uref = x.float() @ w.float().t() + b
-    check("gelu_pre", u, uref, dtype)
-    check("gelu_out", a, torch.nn.functional.gelu(uref), dtype)
+    uref = (x.float() @ w.float().t() + b).requires_grad_(True)
+    aref = torch.nn.functional.gelu(uref)
+    aref.backward(torch.ones_like(aref))
+    check("gelu_out", a, aref.detach(), dtype)
+    check("gelu_deriv", u, uref.grad, dtype)          # aux keeps gelu'(pre-activation) for the backward epilogue
     # dgelu: d_u = (d_a @ W2) * gelu'(u)
     da, w2 = rnd(M, K, dtype=dtype, seed=13), rnd(K, N, dtype=dtype, seed=14, s=0.2)
     du = torch.empty(M, N, device=DEV, dtype=dtype)
     o.gemm(da, w2, du, M, N, K, b_km=True, aux=u, epi=o.EPI_DGELU)
-    uu = u.float().clone().requires_grad_(True)
-    torch.nn.functional.gelu(uu).backward(da.float() @ w2.float())
-    check("dgelu", du, uu.grad, dtype)
+    check("dgelu", du, (da.float() @ w2.float()) * uref.grad, dtype)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
