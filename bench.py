@@ -138,6 +138,7 @@ def main():
     ap.add_argument("--breakdown-json", default=None, help="write the per-kernel breakdown here")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the whole train step as one hipGraph (auto: on for 1 GPU, off for N>1)")
+    ap.add_argument("--no-pipeline", action="store_true", help="diagnostic: no backward pipeline (wgrad/AdamW after backward, same stream)")
     ap.add_argument("--chunk-melems", type=int, default=40, help="backward-pipeline slice size in Mi elements")
     ap.add_argument("--no-streams", action="store_true", help="run the vision stream on the main HIP stream")
     args = ap.parse_args()
@@ -172,8 +173,8 @@ def main():
     # gradients are finalised slice by slice on a third stream during backward: grouped wgrad GEMMs -> column
     # reductions -> (N>1) RCCL all-reduce of the slice -> fused AdamW on the slice
     compress = {"auto": "bf16" if world > 1 else None, "none": None, "bf16": "bf16"}[args.grad_compress]
-    pipe = BackwardPipeline(model.engine, optimizer=opt, chunk_elems=args.chunk_melems << 20, compress=compress,
-                            force_collective=force_dist)
+    pipe = None if args.no_pipeline else BackwardPipeline(model.engine, optimizer=opt, chunk_elems=args.chunk_melems << 20,
+                                                          compress=compress, force_collective=force_dist)
 
     def step():
         loss, _ = model(**batch)
@@ -190,17 +191,28 @@ def main():
         torch.cuda.synchronize()
 
     eager_step = step
-    use_graph = args.graph == "on" or (args.graph == "auto" and world == 1 and not force_dist)
+    # hipGraph replay is the default at every N: ~1000 launches cost ~20 ms of host time per step when issued from Python,
+    # more than the GPU needs to execute them.  At N>1 the RCCL all-reduces of the backward pipeline are captured with the
+    # rest of the step (stream capture of RCCL collectives, as used for graph-mode serving on this stack); if capture is
+    # refused the run falls back to eager issue and says so in config.hip_graph.
+    use_graph = args.graph in ("on", "auto")
     for _ in range(max(args.warmup, 2) if use_graph else args.warmup):
         loss = step()
     if use_graph:
-        # The step is ~1000 kernel launches; issued from Python they cost ~18 ms of host time.  Capture one full step
-        # (forward, backward on both HIP streams, fused AdamW) and replay it: same kernels, same work, no host in the loop.
-        # Device-resident state (dropout offset, AdamW step counter) advances inside the graph.
+        # Capture one full step (forward, backward on both HIP streams, pipelined all-reduce + fused AdamW) and replay it:
+        # same kernels, same work, no host in the loop.  Device-resident state (dropout offset, AdamW step counter)
+        # advances inside the graph.
         from gst_visdial_amd.graph import GraphedStep
-        step = GraphedStep(eager_step, warmup=0)
-        for _ in range(args.warmup):
-            loss = step()
+        try:
+            step = GraphedStep(eager_step, warmup=0)
+            for _ in range(args.warmup):
+                loss = step()
+        except Exception as ex:          # noqa: BLE001 -- any capture failure: keep going eagerly
+            sys.stderr.write("bench: hipGraph capture failed (%s: %s); falling back to eager issue\n" % (type(ex).__name__, ex))
+            torch.cuda.synchronize()
+            step, use_graph = eager_step, False
+            for _ in range(args.warmup):
+                loss = step()
     barrier()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()

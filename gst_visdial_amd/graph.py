@@ -16,7 +16,10 @@ class GraphedStep(object):
             self.out = step_fn()
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # with a process group alive its watchdog thread polls events concurrently: keep the capture's error mode local
+        # to this thread so that polling cannot invalidate it
+        dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local" if dist_on else "global"):
             self.out = step_fn()
 
     def __call__(self):

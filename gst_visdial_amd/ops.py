@@ -225,7 +225,7 @@ def ln_fwd(**kw):
     d = _ln_desc(**kw)
     e0 = _prof_begin()
     L.check("gstvd_ln_fwd", lib.gstvd_ln_fwd(C.byref(d), _stream()))
-    _prof_end(e0, "ln_fwd", 0.0, 3.0 * d.M * d.H * (2 if d.dtype == BF16 else 4))
+    _prof_end(e0, "ln_fwd", 0.0, 3.0 * d.M * d.H * (2 if d.dtype == BF16 else 4), (d.M, d.H, d.mode))
 
 
 def ln_bwd_blocks(M):
@@ -243,7 +243,7 @@ def ln_bwd(fwd_kw, dy, partial, dres=None, dx=None, dword=None, dpos=None, dtt=N
     b.dword, b.dpos, b.dtt, b.dtt_ext = _p(dword), _p(dpos), _p(dtt), _p(dtt_ext)
     e0 = _prof_begin()
     L.check("gstvd_ln_bwd", lib.gstvd_ln_bwd(C.byref(b), _stream()))
-    _prof_end(e0, "ln_bwd", 0.0, 5.0 * b.f.M * b.f.H * (2 if b.f.dtype == BF16 else 4))
+    _prof_end(e0, "ln_bwd", 0.0, 5.0 * b.f.M * b.f.H * (2 if b.f.dtype == BF16 else 4), (b.f.M, b.f.H, b.f.mode))
 
 
 def colsum_partials(partial, nblk, nvec, H, out0, out1, out2, accumulate):
@@ -377,7 +377,7 @@ def attn_fwd(a):
     lib = L.load()
     e0 = _prof_begin()
     L.check("gstvd_attn_fwd", lib.gstvd_attn_fwd(C.byref(a), _stream()))
-    _prof_end(e0, "attn_fwd_d%d" % a.d, 4.0 * a.B * a.nh * a.Lq * a.Lk * a.d)
+    _prof_end(e0, "attn_fwd_d%d" % a.d, 4.0 * a.B * a.nh * a.Lq * a.Lk * a.d, 0.0, (a.B, a.nh, a.Lq, a.Lk))
 
 
 def attn_bwd(a, dO, dQ, dK, dV, delta, lddo=None, lddq=None, lddk=None, lddv=None):
@@ -389,7 +389,7 @@ def attn_bwd(a, dO, dQ, dK, dV, delta, lddo=None, lddq=None, lddk=None, lddv=Non
     a.lddv = dV.stride(-2) if lddv is None else lddv
     e0 = _prof_begin()
     L.check("gstvd_attn_bwd", lib.gstvd_attn_bwd(C.byref(a), _stream()))
-    _prof_end(e0, "attn_bwd_d%d" % a.d, 14.0 * a.B * a.nh * a.Lq * a.Lk * a.d)
+    _prof_end(e0, "attn_bwd_d%d" % a.d, 14.0 * a.B * a.nh * a.Lq * a.Lk * a.d, 0.0, (a.B, a.nh, a.Lq, a.Lk))
 
 
 def ce_fwd(logits, labels, M, V, row_loss, lse, stats, ignore_index=0):
