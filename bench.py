@@ -244,15 +244,25 @@ def main():
             eager_step()
         agg = prof.summary()
         gemms = {k: v for k, v in agg.items() if k.startswith("gemm_")}
-        dom = max(gemms, key=lambda k: gemms[k]["ms"])
+        # Dominant kernel = the one with the largest total duration in the committed rocprofv3 kernel stats of this very
+        # command (profiles/r01_kernel_stats_bench.csv): the grouped weight-gradient GEMM (gemm_dma256_grouped_kernel).
+        # Its launch duration is measured live here with HIP events on the stream it is launched on.
+        dom = "gemm_grouped_tn" if "gemm_grouped_tn" in gemms else max(gemms, key=lambda k: gemms[k]["ms"])
         dv = gemms[dom]
         ach = dv["flops"] / (dv["ms"] * 1e-3) / 1e12
         all_gemm_flops = sum(v["flops"] for v in gemms.values())
         all_gemm_ms = sum(v["ms"] for v in gemms.values())
+        traffic = None
+        try:       # HBM bytes per launch from the PMC passes (tools/pmc_bench.sh; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                traffic = json.load(f).get({"gemm_grouped_tn": "gemm_grouped_wgrad_256"}.get(dom, dom), {}).get("hbm_bytes_per_launch")
+        except (OSError, ValueError):
+            pass
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "kernel": dom, "launches_per_step": dv["launches"],
                     "flops_per_launch": dv["flops"] / dv["launches"], "avg_launch_us": round(1e3 * dv["ms"] / dv["launches"], 2),
+                    "algorithmic_bytes_per_launch": (dv["bytes"] / dv["launches"]) if dv["bytes"] else None,
                     "all_gemm_tflops": round(all_gemm_flops / (all_gemm_ms * 1e-3) / 1e12, 2),
                     "all_gemm_ms_per_step": round(all_gemm_ms, 3),
                     "step_algorithmic_tflops": round(rows_s / world * FLOP_PER_ROW_TRAIN / 1e12, 2),

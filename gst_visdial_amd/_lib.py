@@ -68,6 +68,8 @@ SIGNATURES = {
     "gstvd_abi_version": (_i32, []),
     "gstvd_build_arch": (C.c_char_p, []),
     "gstvd_gemm": (_i32, [C.POINTER(GemmDesc), _vp]),
+    "gstvd_gemm_splitk_ws_bytes": (_i64, [_i64, _i64, _i32]),
+    "gstvd_gemm_splitk": (_i32, [_vp, _i32, _vp, _i64, _vp]),
     "gstvd_gemm_group_tile": (_i32, []),
     "gstvd_gemm_grouped": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp]),
     "gstvd_ln_fwd": (_i32, [C.POINTER(LnDesc), _vp]),

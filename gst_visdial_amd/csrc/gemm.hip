@@ -126,7 +126,7 @@ static int launch_dtype(const GemmP& p, int64_t batch, int akm, int bkm, hipStre
   return launch_layout<T, OT, true, false>(p, batch, s);
 }
 
-extern "C" int gstvd_gemm(const gstvd_gemm_t* g, gstvd_stream_t stream) {
+static int gemm_params(const gstvd_gemm_t* g, GemmP& p) {
   if (!g || !g->A || !g->B || !g->C) return GSTVD_E_NULL;
   if (g->M <= 0 || g->N <= 0 || g->K <= 0 || g->batch <= 0) return GSTVD_E_SHAPE;
   const int ve = g->dtype_in == GSTVD_BF16 ? 8 : 4;
@@ -140,13 +140,32 @@ extern "C" int gstvd_gemm(const gstvd_gemm_t* g, gstvd_stream_t stream) {
   if ((g->epilogue & GSTVD_EPI_BIAS) && !g->bias) return GSTVD_E_NULL;
   if ((g->epilogue & GSTVD_EPI_ADD) && !g->addend) return GSTVD_E_NULL;
   if ((g->epilogue & (GSTVD_EPI_GELU | GSTVD_EPI_DGELU)) && !g->aux) return GSTVD_E_NULL;
-  GemmP p;
   p.A = (const char*)g->A; p.B = (const char*)g->B; p.C = (char*)g->C;
   p.bias = g->bias; p.addend = (const char*)g->addend; p.aux = (char*)g->aux;
   p.M = g->M; p.N = g->N; p.K = g->K;
   p.lda = g->lda; p.ldb = g->ldb; p.ldc = g->ldc; p.ldadd = g->ldadd; p.ldaux = g->ldaux;
   p.sA = g->sA; p.sB = g->sB; p.sC = g->sC; p.sAdd = g->sAdd; p.sAux = g->sAux;
   p.epi = g->epilogue; p.alpha = g->alpha; p.p = g->dropout_p; p.site = g->site; p.rng = g->rng;
+  return 0;
+}
+
+// Skinny, deep problems (few output tiles, long K: the decoder's 400-row GEMMs, the LM-head input gradient): `splits`
+// workgroups share one 64x64 output tile; see dma_tile in gemm_dma.hip.  `ws` is caller-owned scratch of at least
+// gstvd_gemm_splitk_ws_bytes(M, N, splits) bytes, zero-filled once and never shared by launches that can overlap.
+extern "C" int gstvd_gemm_splitk(const gstvd_gemm_t* g, int32_t splits, void* ws, int64_t ws_bytes, gstvd_stream_t stream) {
+  GemmP p;
+  const int rc = gemm_params(g, p);
+  if (rc) return rc;
+  if (splits < 2 || splits > 16 || !ws) return GSTVD_E_SHAPE;
+  if (g->dtype_in != GSTVD_BF16 || g->batch != 1) return GSTVD_E_UNSUPPORTED;
+  if (g->dtype_out != GSTVD_BF16 && g->dtype_out != GSTVD_F32) return GSTVD_E_DTYPE;
+  return gemm_dma_splitk_dispatch(p, g->a_kmajor, g->b_kmajor, g->dtype_out == GSTVD_F32, splits, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int gstvd_gemm(const gstvd_gemm_t* g, gstvd_stream_t stream) {
+  GemmP p;
+  const int prc = gemm_params(g, p);
+  if (prc) return prc;
   hipStream_t s = (hipStream_t)stream;
   if (g->dtype_in == GSTVD_BF16 && (g->dtype_out == GSTVD_BF16 || g->dtype_out == GSTVD_F32)) {
     int rc = gemm_dma256_dispatch(p, g->batch, g->a_kmajor, g->b_kmajor, g->dtype_out == GSTVD_F32, s);

@@ -65,8 +65,12 @@ struct DmaUnits {
 };
 
 // One output tile: the whole K loop + epilogue.  `wg` is the tile's index in the problem's L2-friendly order.
+// Split-K (S > 1): the tile's K range is cut into S contiguous runs of K-tiles, one workgroup each.  Every workgroup
+// parks its fp32 accumulators in `ws`, the last one to arrive (per-tile counter) adds the S partials in split order --
+// so the sum does not depend on arrival order -- and runs the epilogue; it also re-arms the counter.
 template <typename OT, int BM, int BN, int WM, int WN, bool AKM, bool BKM, int NS>
-DEVFN void dma_tile(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char* smem) {
+DEVFN void dma_tile(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char* smem, int S = 1, int split = 0,
+                    float* ws = nullptr, int* cnt = nullptr) {
   constexpr int NT = WM * WN * 64, WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   constexpr int NPA = A_BYTES / (NT * 16), NPB = B_BYTES / (NT * 16), LPS = NPA + NPB;
@@ -93,20 +97,22 @@ DEVFN void dma_tile(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char* s
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int64_t nkt = (p.K + 63) / 64;
+  const int64_t nkt_all = (p.K + 63) / 64, per = (nkt_all + S - 1) / S;
+  const int64_t kt0 = (int64_t)split * per, kt1 = (kt0 + per < nkt_all) ? kt0 + per : nkt_all;
+  const int64_t Kend = (kt1 * 64 < p.K) ? kt1 * 64 : p.K;      // units past this split's K range read the zero page
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s) {
-    ua.issue(s, p.K, smem + s * STAGE, wave);
-    ub.issue(s, p.K, smem + s * STAGE + A_BYTES, wave);
+    ua.issue(kt0 + s, Kend, smem + s * STAGE, wave);
+    ub.issue(kt0 + s, Kend, smem + s * STAGE + A_BYTES, wave);
   }
   int slot = 0, fill = NS - 1;
-  for (int64_t t = 0; t < nkt; ++t) {
+  for (int64_t t = kt0; t < kt1; ++t) {
     // K-tile t has landed for this wave's own DMA once at most (NS-2) younger stages are still in flight
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPS) : "memory");
     __builtin_amdgcn_s_barrier();      // ... and for everybody's; everybody is also done reading slot `fill`
     asm volatile("" ::: "memory");     // s_barrier is IntrNoMem: keep the LDS reads / DMA issue below it
-    ua.issue(t + NS - 1, p.K, smem + fill * STAGE, wave);
-    ub.issue(t + NS - 1, p.K, smem + fill * STAGE + A_BYTES, wave);
+    ua.issue(t + NS - 1, Kend, smem + fill * STAGE, wave);
+    ub.issue(t + NS - 1, Kend, smem + fill * STAGE + A_BYTES, wave);
     const char* cA = smem + slot * STAGE;
     const char* cB = cA + A_BYTES;
 #pragma unroll
@@ -125,6 +131,43 @@ DEVFN void dma_tile(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char* s
     fill = (fill + 1 == NS) ? 0 : fill + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's trailing (zero page) DMAs must land before LDS is released
+
+  if (S > 1) {
+    // Workgroups of one tile may sit on different XCDs (private, mutually non-coherent L2s).  Partials and the arrival
+    // counter therefore move with agent-scope relaxed atomics (sc1: performed at the device coherence point) and the
+    // ordering is explicit -- stores retired (vmcnt 0) by every thread before the counter is bumped -- instead of
+    // agent-scope fences, which write back / invalidate the whole L2 per workgroup.
+    constexpr int APT = MI * NI * 4;                       // fp32 accumulator elements per thread
+    float* mine = ws + (int64_t)(wg * S + split) * NT * APT + tid;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          __hip_atomic_store(mine + ((i * NI + j) * 4 + e) * NT, acc[i][j][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* flag = (int*)smem;
+    if (tid == 0) *flag = __hip_atomic_fetch_add(cnt + wg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*flag != S - 1) return;
+    if (tid == 0) __hip_atomic_store(cnt + wg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < S; ++q) {
+      const float* part = ws + (int64_t)(wg * S + q) * NT * APT + tid;
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[i][j][e] += __hip_atomic_load(part + ((i * NI + j) * 4 + e) * NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 
   const int g = lane >> 4, li = lane & 15;
   const DropKey dk = make_drop((p.epi & GSTVD_EPI_DROPOUT) ? p.p : 0.f, p.site, p.rng);
@@ -145,6 +188,13 @@ template <typename OT, int BM, int BN, int WM, int WN, bool AKM, bool BKM, int N
 __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(GemmP p, int ntn, int nwg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   dma_tile<OT, BM, BN, WM, WN, AKM, BKM, NS>(p, blockIdx.y, xcd_remap(blockIdx.x, nwg), ntn, nwg, smem);
+}
+
+template <typename OT, int BM, int BN, int WM, int WN, bool AKM, bool BKM, int NS>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_dma_splitk_kernel(GemmP p, int ntn, int ntiles, int S, float* ws, int* cnt) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int id = xcd_remap(blockIdx.x, ntiles * S);
+  dma_tile<OT, BM, BN, WM, WN, AKM, BKM, NS>(p, 0, id / S, ntn, ntiles, smem, S, id % S, ws, cnt);
 }
 
 template <typename OT, int BM, int BN, int WM, int WN, bool AKM, bool BKM, int NS>
@@ -180,6 +230,41 @@ static int dma_out(const GemmP& p, int64_t batch, int akm, int bkm, hipStream_t 
   if (!akm && bkm) return dma_layout<OT, false, true>(p, batch, s);
   if (akm && bkm) return dma_layout<OT, true, true>(p, batch, s);
   return dma_layout<OT, true, false>(p, batch, s);
+}
+
+constexpr int SPLITK_MAX_TILES = 1024;      // counters occupy the first 4 KiB of the scratch, partials follow
+
+template <typename OT, bool AKM, bool BKM>
+static int splitk_launch(const GemmP& p, int S, void* ws, int64_t ws_bytes, hipStream_t s) {
+  constexpr int BM = 64, BN = 64, NS = 8, lds = NS * (BM + BN) * 128;
+  auto k = gemm_dma_splitk_kernel<OT, BM, BN, 2, 2, AKM, BKM, NS>;
+  static int attr_rc = ensure_lds(k, lds);
+  if (attr_rc) return attr_rc;
+  const int ntm = (int)((p.M + BM - 1) / BM), ntn = (int)((p.N + BN - 1) / BN), tiles = ntm * ntn;
+  if (ws_bytes < gstvd_gemm_splitk_ws_bytes(p.M, p.N, S)) return GSTVD_E_SHAPE;
+  if (tiles > SPLITK_MAX_TILES) return GSTVD_E_SHAPE;
+  int* cnt = (int*)ws;                                                   // [tiles] arrival counters (zero between launches)
+  float* part = (float*)((char*)ws + SPLITK_MAX_TILES * 4);             // fixed layout: a scratch serves launches of any shape
+  hipLaunchKernelGGL(k, dim3((unsigned)(tiles * S)), dim3(256), lds, s, p, ntn, tiles, S, part, cnt);
+  GSTVD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int64_t gstvd_gemm_splitk_ws_bytes(int64_t M, int64_t N, int32_t splits) {
+  const int64_t tiles = ((M + 63) / 64) * ((N + 63) / 64);
+  return SPLITK_MAX_TILES * 4 + tiles * splits * 64 * 64 * 4;
+}
+
+int gemm_dma_splitk_dispatch(const GemmP& p, int akm, int bkm, int out_f32, int S, void* ws, int64_t ws_bytes, hipStream_t s) {
+  if (akm && !bkm) return GSTVD_E_UNSUPPORTED;
+  if (out_f32) {
+    if (!akm && !bkm) return splitk_launch<float, false, false>(p, S, ws, ws_bytes, s);
+    if (!akm && bkm) return splitk_launch<float, false, true>(p, S, ws, ws_bytes, s);
+    return splitk_launch<float, true, true>(p, S, ws, ws_bytes, s);
+  }
+  if (!akm && !bkm) return splitk_launch<bf16, false, false>(p, S, ws, ws_bytes, s);
+  if (!akm && bkm) return splitk_launch<bf16, false, true>(p, S, ws, ws_bytes, s);
+  return splitk_launch<bf16, true, true>(p, S, ws, ws_bytes, s);
 }
 
 int gemm_dma_dispatch(const GemmP& p, int64_t batch, int akm, int bkm, int out_f32, hipStream_t s) {

@@ -4,6 +4,7 @@ torch is used only as the owner of device memory and of the HIP stream; every fu
 a hand-written gfx950 kernel on `torch.cuda.current_stream()` and raises if the library is missing,
 a tensor is not on the GPU, or the kernel returns a non-zero status.  No fallbacks.
 """
+import os
 import ctypes as C
 
 import torch
@@ -130,10 +131,44 @@ def gemm(A, B, C_out, M, N, K, *, a_km=False, b_km=False, bias=None, addend=None
     d.alpha, d.dropout_p, d.site = alpha, drop_p, site
     d.rng = rng.ptr() if (rng is not None and drop_p > 0) else None
     e0 = _prof_begin()
-    L.check("gstvd_gemm", lib.gstvd_gemm(C.byref(d), _stream()))
-    _prof_end(e0, gemm_tag(d.dtype_in, a_km, b_km, M, N, batch), 2.0 * M * N * K * batch,
+    splits = splitk_plan(d.dtype_in, M, N, K, batch, a_km, b_km)
+    if splits > 1:
+        ws = _splitk_scratch(A.device)
+        L.check("gstvd_gemm_splitk", lib.gstvd_gemm_splitk(C.byref(d), splits, ws.data_ptr(), ws.numel(), _stream()))
+        tag = gemm_tag(d.dtype_in, a_km, b_km, M, N, batch) + "_splitk%d" % splits
+    else:
+        L.check("gstvd_gemm", lib.gstvd_gemm(C.byref(d), _stream()))
+        tag = gemm_tag(d.dtype_in, a_km, b_km, M, N, batch)
+    _prof_end(e0, tag, 2.0 * M * N * K * batch,
               float(batch) * ((M * K + N * K) * A.element_size() + M * N * C_out.element_size()), (M, N, K, batch))
     return C_out
+
+
+SPLITK = int(os.environ.get("GSTVD_GEMM_SPLITK", "1"))
+_SPLITK_WS = {}
+
+
+def splitk_plan(dtype_in, M, N, K, batch, a_km, b_km):
+    """Number of K splits for the 64x64-tile kernel (1 = plain launch).  Skinny and deep only: the tiles must leave
+    most of the 256 CUs idle and each split must still run a ring's worth of K-tiles."""
+    if not SPLITK or dtype_in != BF16 or batch != 1 or (a_km and not b_km):
+        return 1
+    if M >= 256 and N >= 128 and ((M + 127) // 128) * ((N + 127) // 128) >= 96:
+        return 1                                    # the 128 / 256 tile kernels take it
+    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    nkt = (K + 63) // 64
+    s = min(256 // max(tiles, 1), nkt // 10, 8)
+    return s if s >= 2 else 1
+
+
+def _splitk_scratch(device):
+    """Per-stream split-K scratch (launches on one stream never overlap): counters + 256 tile slots, zeroed once."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _SPLITK_WS.get(key)
+    if ws is None:
+        ws = torch.zeros(4096 + 256 * 64 * 64 * 4, dtype=torch.uint8, device=device)
+        _SPLITK_WS[key] = ws
+    return ws
 
 
 class GemmGroup(object):
@@ -176,7 +211,8 @@ class GemmGroup(object):
         hit = self.cache.get(key)
         if hit is None:
             arr = (L.GemmDesc * len(key))()
-            offs, tiles, flops = [], 0, 0.0
+            offs, tiles, flops, nbytes = [], 0, 0.0, 0.0
+            esz_in, esz_out = (2 if self.dtype_in == BF16 else 4), (2 if self.dtype_out == BF16 else 4)
             T = int(L.load().gstvd_gemm_group_tile())
             for d, (a, b, c, M, N, K, lda, ldb, ldc, acc) in zip(arr, key):
                 d.A, d.B, d.C, d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.batch = a, b, c, M, N, K, lda, ldb, ldc, 1
@@ -186,18 +222,19 @@ class GemmGroup(object):
                 offs.append(tiles)
                 tiles += ((M + T - 1) // T) * ((N + T - 1) // T)
                 flops += 2.0 * M * N * K
+                nbytes += esz_in * (M * K + K * N) + esz_out * M * N * (2 if acc else 1)
             tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
             off = torch.tensor(offs, dtype=torch.int32).to(self.device)
-            hit = (tab, off, len(key), tiles, flops)
+            hit = (tab, off, len(key), tiles, flops, nbytes)
             if len(self.cache) > 64:
                 self.cache.clear()
             self.cache[key] = hit
-        tab, off, n, tiles, flops = hit
+        tab, off, n, tiles, flops, nbytes = hit
         lib = L.load()
         e0 = _prof_begin()
         L.check("gstvd_gemm_grouped", lib.gstvd_gemm_grouped(tab.data_ptr(), off.data_ptr(), n, tiles, self.dtype_in, self.dtype_out,
                                                              int(self.a_km), int(self.b_km), _stream()))
-        _prof_end(e0, "gemm_grouped_%s" % ("tn" if self.a_km else "nt"), flops, 0.0, (n, tiles))
+        _prof_end(e0, "gemm_grouped_%s" % ("tn" if self.a_km else "nt"), flops, nbytes, (n, tiles))
         self.items = []
 
 

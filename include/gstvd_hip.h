@@ -67,6 +67,16 @@ typedef struct {
 } gstvd_gemm_t;
 int gstvd_gemm(const gstvd_gemm_t* g, gstvd_stream_t s);
 
+/* Split-K form of the same problem (bf16 inputs, batch = 1): for skinny, deep problems -- the decoder's 400-row
+ * GEMMs with K >= 2304 and the LM-head input gradient (K = 30528) -- whose few 64x64 output tiles cannot keep the chip's
+ * LDS fill paths busy.  `splits` workgroups share a tile, park fp32 partials in `ws`, the last to arrive adds them in
+ * split order (result independent of arrival order) and runs the epilogue.  `ws`: caller-owned device scratch of at
+ * least gstvd_gemm_splitk_ws_bytes() bytes (4 KiB of per-tile arrival counters, then the partials; at most 1024 tiles),
+ * zero-filled once (the kernel leaves its counters zero; one scratch serves launches of any shape), never shared by
+ * launches that may run concurrently (one per stream). */
+int64_t gstvd_gemm_splitk_ws_bytes(int64_t M, int64_t N, int32_t splits);
+int gstvd_gemm_splitk(const gstvd_gemm_t* g, int32_t splits, void* ws, int64_t ws_bytes, gstvd_stream_t s);
+
 /* Grouped form: `table_dev` is a DEVICE array of nprob independent problems (batch ignored, = 1) that share dtypes
  * and operand layouts; they run as ONE launch over all their 128x128 tiles.  tile_off_dev[i] = first tile id of
  * problem i (ceil(M/128)*ceil(N/128) tiles each), device int32[nprob].  The engine uses it for the deferred

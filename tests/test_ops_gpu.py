@@ -104,6 +104,41 @@ def test_gemm_gelu_epilogues(dtype):
     check("dgelu", du, (da.float() @ w2.float()) * uref.grad, dtype)
 
 
+@pytest.mark.parametrize("lay", ["nt", "nn", "tn"])
+@pytest.mark.parametrize("shape", [(400, 768, 3072), (100, 200, 1992), (64, 64, 30528), (37, 132, 2304)])
+def test_gemm_splitk_matches_single_pass(lay, shape):
+    """Skinny, deep bf16 problems take the split-K kernel (gstvd_gemm_splitk); same result as one pass, epilogue included,
+    and bit-identical from run to run (partials are added in split order, not arrival order)."""
+    o = ops()
+    M, N, K = shape
+    a_km, b_km = (lay == "tn"), (lay in ("nn", "tn"))
+    if a_km and M % 8:
+        M = (M + 7) // 8 * 8
+    if b_km and N % 8:
+        N = (N + 7) // 8 * 8
+    N = (N + 3) // 4 * 4
+    A = rnd(*((K, M) if a_km else (M, K)), dtype=torch.bfloat16, seed=31, s=0.5)
+    B = rnd(*((K, N) if b_km else (N, K)), dtype=torch.bfloat16, seed=32, s=0.5)
+    bias, add = rnd(N, seed=33), rnd(M, N, dtype=torch.bfloat16, seed=34)
+    assert o.splitk_plan(o.BF16, M, N, K, 1, a_km, b_km) > 1
+    outs = []
+    for rep in range(3):
+        Cs = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        o.gemm(A, B, Cs, M, N, K, a_km=a_km, b_km=b_km, bias=bias, addend=add)
+        outs.append(Cs)
+    ref = (A.float().t() if a_km else A.float()) @ (B.float() if b_km else B.float().t()) + bias + add.float()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    check("splitk", outs[0], ref, torch.bfloat16)
+    old, o.SPLITK = o.SPLITK, 0
+    try:
+        C1 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        o.gemm(A, B, C1, M, N, K, a_km=a_km, b_km=b_km, bias=bias, addend=add)
+    finally:
+        o.SPLITK = old
+    # fp32 accumulation in a different order: identical up to the final bf16 rounding
+    assert (outs[0].float() - C1.float()).abs().max() <= 2.0 ** -7 * ref.abs().max()
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_batched_and_dropout(dtype):
     o = ops()
