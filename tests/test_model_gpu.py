@@ -283,3 +283,32 @@ def test_score_candidates_equals_per_row_reference_path():
     assert maxerr(fast, slow) < 2e-4
     from gst_visdial_amd.metrics import scores_to_ranks
     assert torch.equal(scores_to_ranks(fast.view(1, E, G).cpu()), scores_to_ranks(slow.view(1, E, G).cpu()))
+
+
+def test_two_stream_schedule_matches_single_stream():
+    """Vision half of the encoder on its own HIP stream (forward and backward) == everything on one stream."""
+    from gst_visdial_amd.optim import FusedAdamW
+    s = sc()
+    g = load_npz("tiny_train.npz")
+
+    def run(streams):
+        model, params, cfg = s.build_tiny_model("fp32", DEV, seed=5)
+        model.engine.use_streams = streams
+        model.train()
+        kw = s.golden_batch(g, DEV)
+        opt = FusedAdamW(model, lr=1e-3)
+        losses = []
+        for _ in range(2):
+            loss, _ = model(**kw)
+            loss.backward()
+            opt.step()
+            opt.zero_grad()
+            losses.append(loss.item())
+        torch.cuda.synchronize()
+        return losses, model.engine.flat.P.clone()
+
+    l0, p0 = run(False)
+    l1, p1 = run(True)
+    for a, b in zip(l0, l1):
+        assert abs(a - b) < 1e-5 * max(1.0, abs(a)), (l0, l1)
+    assert maxerr(p0, p1) < 1e-6
