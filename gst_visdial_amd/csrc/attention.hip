@@ -55,6 +55,34 @@ DEVFN void stage64(const T* g, int64_t ld, int r0, int rmax, char* img_row, char
   }
 }
 
+// Two-phase form of stage64 for software pipelining: `load` issues the chunk's global loads into registers (they stay in
+// flight while the previous chunk is being consumed), `store` writes them into the LDS image(s) after the barrier.
+template <typename T, int D> struct Stage64 {
+  static constexpr int VE = 16 / sizeof(T), VPR = D / VE, TOT = 64 * VPR, NV = TOT / 256;
+  static_assert(TOT % 256 == 0, "chunk must split evenly over 256 threads");
+  u32x4 v[NV];
+  DEVFN void load(const T* g, int64_t ld, int r0, int rmax, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + i * 256, row = idx / VPR, cv = idx % VPR;
+      v[i] = (u32x4){0u, 0u, 0u, 0u};
+      if (r0 + row < rmax) v[i] = *(const u32x4*)(g + (int64_t)(r0 + row) * ld + cv * VE);
+    }
+  }
+  DEVFN void store(char* img_row, char* img_tr, int tid) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + i * 256, row = idx / VPR, cv = idx % VPR;
+      if (Img<T, D>::BF) {
+        if (img_row) *(u32x4*)(img_row + Img<T, D>::row_off(row, cv)) = v[i];
+        if (img_tr) *(u32x4*)(img_tr + Img<T, D>::tr_off(row, cv * 8)) = v[i];
+      } else {
+        *(u32x4*)(img_row + row * Img<T, D>::RB + cv * 16) = v[i];
+      }
+    }
+  }
+};
+
 // per-lane register copy of one row of a [rows, ld] matrix laid out as the MFMA operand that contracts over d:
 //   bf16: NF = D/32 fragments of 8 (d = kk*32 + 8g + j);  f32: NF = D/4 scalars (d = g*(D/4) + ks)
 template <typename T, int D> struct RowFrag;
@@ -180,17 +208,26 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(gstvd_attn_t a) {
 #pragma unroll
   for (int i = 0; i < D / 16; ++i) accO[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int c0 = 0; c0 < a.Lk; c0 += 64) {
-    __syncthreads();
-    stage64<T, D>(Kb, a.ldk, c0, a.Lk, sK, nullptr, tid);
-    stage64<T, D>(Vb, a.ldv, c0, a.Lk, Img<T, D>::BF ? nullptr : sV, Img<T, D>::BF ? sV : nullptr, tid);
+  // chunk c+1's K / V / mask loads are issued right after chunk c has been parked in LDS and fly during its compute
+  Stage64<T, D> pk, pv;
+  float pm = 2.f;
+  auto prefetch = [&](int c0) {
+    pk.load(Kb, a.ldk, c0, a.Lk, tid);
+    pv.load(Vb, a.ldv, c0, a.Lk, tid);
     if (tid < 64) {
       const int key = c0 + tid;
-      float mv = 2.f;
-      if (key < a.Lk) mv = (a.key_mask == nullptr || a.key_mask[(int64_t)bk * a.Lk + key] != 0.f) ? 0.f : 1.f;
-      smask[tid] = mv;
+      pm = 2.f;
+      if (key < a.Lk) pm = (a.key_mask == nullptr || a.key_mask[(int64_t)bk * a.Lk + key] != 0.f) ? 0.f : 1.f;
     }
+  };
+  prefetch(0);
+  for (int c0 = 0; c0 < a.Lk; c0 += 64) {
     __syncthreads();
+    pk.store(sK, nullptr, tid);
+    pv.store(Img<T, D>::BF ? nullptr : sV, Img<T, D>::BF ? sV : nullptr, tid);
+    if (tid < 64) smask[tid] = pm;
+    __syncthreads();
+    if (c0 + 64 < a.Lk) prefetch(c0 + 64);
     const int ntile = (a.Lk - c0 + 15) / 16 < 4 ? (a.Lk - c0 + 15) / 16 : 4;
     for (int t = 0; t < ntile; ++t) {
       f32x4 s = first_product<T, D>(sK, t * 16, qf, lane);
@@ -270,17 +307,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(gstvd_attn_t a) {
 #pragma unroll
   for (int i = 0; i < D / 16; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int c0 = 0; c0 < a.Lk; c0 += 64) {
-    __syncthreads();
-    stage64<T, D>(Kb, a.ldk, c0, a.Lk, sKr, BF ? sKt : nullptr, tid);
-    stage64<T, D>(Vb, a.ldv, c0, a.Lk, sVr, nullptr, tid);
+  Stage64<T, D> pk, pv;
+  float pm = 2.f;
+  auto prefetch = [&](int c0) {
+    pk.load(Kb, a.ldk, c0, a.Lk, tid);
+    pv.load(Vb, a.ldv, c0, a.Lk, tid);
     if (tid < 64) {
       const int key = c0 + tid;
-      float mv = 2.f;
-      if (key < a.Lk) mv = (a.key_mask == nullptr || a.key_mask[(int64_t)b * a.Lk + key] != 0.f) ? 0.f : 1.f;
-      smask[tid] = mv;
+      pm = 2.f;
+      if (key < a.Lk) pm = (a.key_mask == nullptr || a.key_mask[(int64_t)b * a.Lk + key] != 0.f) ? 0.f : 1.f;
     }
+  };
+  prefetch(0);
+  for (int c0 = 0; c0 < a.Lk; c0 += 64) {
     __syncthreads();
+    pk.store(sKr, BF ? sKt : nullptr, tid);
+    pv.store(sVr, nullptr, tid);
+    if (tid < 64) smask[tid] = pm;
+    __syncthreads();
+    if (c0 + 64 < a.Lk) prefetch(c0 + 64);
     const int ntile = (a.Lk - c0 + 15) / 16 < 4 ? (a.Lk - c0 + 15) / 16 : 4;
     for (int t = 0; t < ntile; ++t) {
       const f32x4 s = first_product<T, D>(sKr, t * 16, qf, lane);
@@ -341,16 +386,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(gstvd_attn_t a) {
 #pragma unroll
   for (int i = 0; i < D / 16; ++i) accK[i] = accV[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int c0 = 0; c0 < a.Lq; c0 += 64) {
-    __syncthreads();
-    stage64<T, D>(Qb, a.ldq, c0, a.Lq, sQr, BF ? sQt : nullptr, tid);
-    stage64<T, D>(dOb, a.lddo, c0, a.Lq, sOr, BF ? sOt : nullptr, tid);
+  Stage64<T, D> pq, po;
+  float plse = INFINITY, pdel = 0.f;
+  auto prefetch = [&](int c0) {
+    pq.load(Qb, a.ldq, c0, a.Lq, tid);
+    po.load(dOb, a.lddo, c0, a.Lq, tid);
     if (tid < 64) {
       const int qq = c0 + tid;
-      sLse[tid] = qq < a.Lq ? a.LSE[stat0 + qq] : INFINITY;    // +inf => p = 0 for padded query rows
-      sDel[tid] = qq < a.Lq ? a.delta[stat0 + qq] : 0.f;
+      plse = qq < a.Lq ? a.LSE[stat0 + qq] : INFINITY;         // +inf => p = 0 for padded query rows
+      pdel = qq < a.Lq ? a.delta[stat0 + qq] : 0.f;
     }
+  };
+  prefetch(0);
+  for (int c0 = 0; c0 < a.Lq; c0 += 64) {
     __syncthreads();
+    pq.store(sQr, BF ? sQt : nullptr, tid);
+    po.store(sOr, BF ? sOt : nullptr, tid);
+    if (tid < 64) { sLse[tid] = plse; sDel[tid] = pdel; }
+    __syncthreads();
+    if (c0 + 64 < a.Lq) prefetch(c0 + 64);
     const int ntile = (a.Lq - c0 + 15) / 16 < 4 ? (a.Lq - c0 + 15) / 16 : 4;
     for (int t = 0; t < ntile; ++t) {
       const f32x4 s = first_product<T, D>(sQr, t * 16, kf, lane);     // [q = 4g+r][key = li]
