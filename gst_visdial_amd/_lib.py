@@ -92,6 +92,7 @@ SIGNATURES = {
     "gstvd_rng_advance": (_i32, [_vp, _vp]),
     "gstvd_dropout_mask": (_i32, [_vp, _i64, _f32, _u32, _vp, _vp]),
     "gstvd_adamw": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _f32, _f32, _f32, _vp, _f32, _i64, _vp]),
+    "gstvd_adamw_bf16grad": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _f32, _f32, _f32, _vp, _f32, _i64, _vp]),
 }
 
 _STATUS = {-1: "GSTVD_E_DTYPE", -2: "GSTVD_E_SHAPE", -3: "GSTVD_E_ALIGN", -4: "GSTVD_E_NULL", -5: "GSTVD_E_UNSUPPORTED"}

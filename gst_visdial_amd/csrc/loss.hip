@@ -121,9 +121,12 @@ __global__ void dropout_mask_kernel(float* out, int64_t n, float p, uint32_t sit
 
 // AdamW: pytorch_transformers==1.2.0 optimization.AdamW.step (train_gen.py:16,247).  Segments are 4-element aligned
 // (the flat layout aligns every tensor to 64 elements), so one lookup serves a 16-byte vector.
-__global__ __launch_bounds__(256) void adamw_kernel(float* param, const float* grad, float* m, float* v, bf16* shadow, int64_t n,
+// GT = float: grad is the flat fp32 gradient buffer (same indexing as param).  GT = bf16: grad points at the bf16 copy of
+// the slice that was just all-reduced; element i of the flat buffers is grad[i - gorigin].
+template <typename GT>
+__global__ __launch_bounds__(256) void adamw_kernel(float* param, const GT* grad, float* m, float* v, bf16* shadow, int64_t n,
                                                     const int64_t* seg_end, const float* hp, int64_t nseg, float b1, float b2,
-                                                    float eps, const float* step, float gscale, int64_t base) {
+                                                    float eps, const float* step, float gscale, int64_t base, int64_t gorigin) {
   // the launch covers flat elements [base, n) of the buffers (pointers are the buffers' starts); segment ends are absolute
   const int64_t i = base + ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= n) return;
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* param, const float* g
   const float t = step[0];
   const float bc = sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
   if (i + 3 < n && seg_end[lo] >= i + 4) {
-    const f32x4 g4 = *(const f32x4*)(grad + i) * gscale;
+    const f32x4 g4 = ld4(grad + (i - gorigin)) * gscale;
     const f32x4 m4 = *(const f32x4*)(m + i) * b1 + g4 * (1.f - b1);
     const f32x4 v4 = *(const f32x4*)(v + i) * b2 + g4 * g4 * (1.f - b2);
     f32x4 p4 = *(const f32x4*)(param + i);
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* param, const float* g
     const int64_t k = i + e;
     while (seg < nseg - 1 && seg_end[seg] <= k) ++seg;
     const float lr_ = hp[2 * seg], wd_ = hp[2 * seg + 1];
-    const float gg = grad[k] * gscale;
+    const float gg = (float)grad[k - gorigin] * gscale;
     const float mm = m[k] * b1 + (1.f - b1) * gg;
     const float vv = v[k] * b2 + (1.f - b2) * gg * gg;
     m[k] = mm; v[k] = vv;
@@ -278,8 +281,21 @@ extern "C" int gstvd_adamw(float* param, const float* grad, float* m, float* v, 
                            const float* step, float grad_scale, int64_t begin, gstvd_stream_t stream) {
   if (!param || !grad || !m || !v || !seg_end || !hp || !step) return GSTVD_E_NULL;
   if (n <= 0 || nseg <= 0 || begin < 0 || begin >= n || (begin % 4)) return GSTVD_E_SHAPE;
-  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n - begin + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v,
-                     (bf16*)shadow_bf16, n, seg_end, hp, nseg, beta1, beta2, eps, step, grad_scale, begin);
+  hipLaunchKernelGGL(adamw_kernel<float>, dim3((unsigned)((n - begin + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, param, grad,
+                     m, v, (bf16*)shadow_bf16, n, seg_end, hp, nseg, beta1, beta2, eps, step, grad_scale, begin, (int64_t)0);
+  GSTVD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gstvd_adamw_bf16grad(float* param, const void* grad_bf16, int64_t grad_origin, float* m, float* v, void* shadow_bf16,
+                                    int64_t n, const int64_t* seg_end, const float* hp, int64_t nseg, float beta1, float beta2,
+                                    float eps, const float* step, float grad_scale, int64_t begin, gstvd_stream_t stream) {
+  if (!param || !grad_bf16 || !m || !v || !seg_end || !hp || !step) return GSTVD_E_NULL;
+  if (n <= 0 || nseg <= 0 || begin < 0 || begin >= n || (begin % 4) || grad_origin > begin || (grad_origin % 4)) return GSTVD_E_SHAPE;
+  if ((uintptr_t)grad_bf16 & 7) return GSTVD_E_ALIGN;
+  hipLaunchKernelGGL(adamw_kernel<bf16>, dim3((unsigned)((n - begin + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, param,
+                     (const bf16*)grad_bf16, m, v, (bf16*)shadow_bf16, n, seg_end, hp, nseg, beta1, beta2, eps, step, grad_scale, begin,
+                     grad_origin);
   GSTVD_LAUNCH_CHECK();
   return 0;
 }

@@ -473,11 +473,20 @@ def dropout_mask(n, p, site, rng, device):
     return out
 
 
-def adamw(param, grad, m, v, shadow, seg_end, hp, step, beta1=0.9, beta2=0.999, eps=1e-6, grad_scale=1.0, begin=0, end=None):
-    """Fused AdamW over flat elements [begin, end) of the buffers."""
+def adamw(param, grad, m, v, shadow, seg_end, hp, step, beta1=0.9, beta2=0.999, eps=1e-6, grad_scale=1.0, begin=0, end=None,
+          grad_origin=0):
+    """Fused AdamW over flat elements [begin, end) of the buffers.  `grad` is the flat fp32 gradient buffer, or a bf16
+    tensor holding flat elements [grad_origin, grad_origin + grad.numel()) (the all-reduced compressed slice)."""
     lib = L.load()
     n = param.numel() if end is None else end
     e0 = _prof_begin()
-    L.check("gstvd_adamw", lib.gstvd_adamw(_p(param), _p(grad), _p(m), _p(v), _p(shadow), n, _p(seg_end), _p(hp),
-                                           seg_end.numel(), beta1, beta2, eps, _p(step), grad_scale, begin, _stream()))
+    if grad.dtype == torch.bfloat16:
+        if grad_origin + grad.numel() < n:
+            raise ValueError("bf16 gradient slice does not cover [begin, end)")
+        L.check("gstvd_adamw_bf16grad", lib.gstvd_adamw_bf16grad(_p(param), _p(grad), grad_origin, _p(m), _p(v), _p(shadow), n,
+                                                                 _p(seg_end), _p(hp), seg_end.numel(), beta1, beta2, eps, _p(step),
+                                                                 grad_scale, begin, _stream()))
+    else:
+        L.check("gstvd_adamw", lib.gstvd_adamw(_p(param), _p(grad), _p(m), _p(v), _p(shadow), n, _p(seg_end), _p(hp),
+                                               seg_end.numel(), beta1, beta2, eps, _p(step), grad_scale, begin, _stream()))
     _prof_end(e0, "adamw", 0.0, (n - begin) * (30.0 if shadow is not None else 28.0))

@@ -104,11 +104,16 @@ class FusedAdamW(object):
         self.opt_step += 1
         self.step_dev.add_(1.0)
 
-    def apply_range(self, lo, hi):
-        """AdamW on flat elements [lo, hi) -- used slice by slice by the backward pipeline."""
+    def apply_range(self, lo, hi, grad_bf16=None):
+        """AdamW on flat elements [lo, hi) -- used slice by slice by the backward pipeline.  `grad_bf16`: the slice's
+        gradients as a bf16 tensor of hi-lo elements (the all-reduced compressed copy) instead of G[lo:hi]."""
         flat = self.engine.flat
-        ops.adamw(flat.P, flat.G, self.m, self.v, flat.S, self.seg_end, self.hp, self.step_dev, self.betas[0],
-                  self.betas[1], self.eps, self.grad_scale, begin=lo, end=hi)
+        if grad_bf16 is not None:
+            ops.adamw(flat.P, grad_bf16, self.m, self.v, flat.S, self.seg_end, self.hp, self.step_dev, self.betas[0],
+                      self.betas[1], self.eps, self.grad_scale, begin=lo, end=hi, grad_origin=lo)
+        else:
+            ops.adamw(flat.P, flat.G, self.m, self.v, flat.S, self.seg_end, self.hp, self.step_dev, self.betas[0],
+                      self.betas[1], self.eps, self.grad_scale, begin=lo, end=hi)
         if flat.S is not None:
             flat.shadow_version = flat.version()
 

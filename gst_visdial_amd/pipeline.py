@@ -18,10 +18,14 @@ import torch.distributed as dist
 
 
 class BackwardPipeline(object):
-    def __init__(self, engine, optimizer=None, group=None, chunk_elems=40 << 20, compress=None, force_collective=False):
+    def __init__(self, engine, optimizer=None, group=None, chunk_elems=40 << 20, compress=None, force_collective=False,
+                 keep_grads=False):
         self.engine, self.opt, self.group = engine, optimizer, group
         self.chunk = chunk_elems
         self.compress = compress
+        # compress="bf16": the slice is cast to bf16, all-reduced, and (with an optimizer attached) consumed by AdamW
+        # straight from the bf16 copy; the fp32 buffer G / `.grad` then keeps the LOCAL gradients unless keep_grads
+        self.keep_grads = keep_grads
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.collective = self.world > 1 or (force_collective and dist.is_initialized())
         self.hi = None
@@ -45,6 +49,7 @@ class BackwardPipeline(object):
         """Runs on the auxiliary stream, after the slice's weight-gradient GEMMs and column reductions."""
         flat = self.engine.flat
         self.slices.append((lo, hi))
+        reduced_bf16 = None
         if self.collective:
             sl = flat.G[lo:hi]
             if self.compress == "bf16":
@@ -52,11 +57,14 @@ class BackwardPipeline(object):
                 tmp = torch.empty(hi - lo, dtype=torch.bfloat16, device=sl.device)
                 ops.cast(sl, tmp)
                 dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group)
-                ops.cast(tmp, sl)
+                if self.opt is None or self.keep_grads:
+                    ops.cast(tmp, sl)
+                else:
+                    reduced_bf16 = tmp
             else:
                 dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group)
         if self.opt is not None:
-            self.opt.apply_range(lo, hi)
+            self.opt.apply_range(lo, hi, grad_bf16=reduced_bf16)
         self.hi = lo
 
     def end(self):

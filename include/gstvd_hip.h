@@ -229,6 +229,12 @@ int gstvd_dropout_mask(float* out, int64_t n, float p, uint32_t site, const uint
 int gstvd_adamw(float* param, const float* grad, float* m, float* v, void* shadow_bf16, int64_t n,
                 const int64_t* seg_end, const float* hp, int64_t nseg, float beta1, float beta2, float eps,
                 const float* step /* device scalar, 1-based */, float grad_scale, int64_t begin, gstvd_stream_t s);
+/* Same update with the gradient taken from a bf16 buffer: flat element i reads grad_bf16[i - grad_origin].  Used at N>1
+ * when the gradient slice travels over RCCL in bf16: the all-reduced bf16 slice feeds AdamW directly instead of being
+ * expanded back into the fp32 gradient buffer first (saves 8 B/param of HBM traffic per step). */
+int gstvd_adamw_bf16grad(float* param, const void* grad_bf16, int64_t grad_origin, float* m, float* v, void* shadow_bf16,
+                         int64_t n, const int64_t* seg_end, const float* hp, int64_t nseg, float beta1, float beta2, float eps,
+                         const float* step, float grad_scale, int64_t begin, gstvd_stream_t s);
 
 #ifdef __cplusplus
 }

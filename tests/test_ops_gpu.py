@@ -421,6 +421,18 @@ def test_cast_roundtrip_and_adamw():
     check("adamw_m", m, mr, torch.float32)
     check("adamw_v", v, vr, torch.float32)
     assert torch.equal(shadow, p.to(torch.bfloat16))
+    # slice [begin, end) fed from a bf16 copy of the slice's gradients (the compressed all-reduce path, N>1):
+    # identical to the fp32-gradient kernel run on the bf16-rounded gradients; elements outside the slice untouched
+    lo, hi = 1000, 4004
+    gb = g0[lo:hi].to(torch.bfloat16)
+    pa, ma, va = p0.clone(), m0.clone(), v0.clone()
+    pb, mb, vb = p0.clone(), m0.clone(), v0.clone()
+    sa, sb = torch.zeros_like(shadow), torch.zeros_like(shadow)
+    gq = g0.clone(); gq[lo:hi] = gb.float()
+    o.adamw(pa, gq, ma, va, sa, seg_end, hp, step, begin=lo, end=hi)
+    o.adamw(pb, gb, mb, vb, sb, seg_end, hp, step, begin=lo, end=hi, grad_origin=lo)
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb) and torch.equal(sa, sb)
+    assert torch.equal(pb[:lo], p0[:lo]) and torch.equal(pb[hi:], p0[hi:])
 
 
 def test_gemm_grouped_matches_individual_launches():
