@@ -16,8 +16,6 @@
 
 __device__ __attribute__((aligned(256))) char g_zero_page[256];
 
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
 
 DEVFN void glds16(const char* src, char* lds_wave_base) {
   glds16_asm(src, __builtin_amdgcn_readfirstlane(lds_addr(lds_wave_base)));

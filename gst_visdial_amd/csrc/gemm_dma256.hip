@@ -1,4 +1,4 @@
-// 256x256x32 bf16 MFMA GEMM tile, 8 waves (each 128x64), LDS-DMA 4-stage ring.
+// 256x256x32 bf16 MFMA GEMM tile, 8 waves (each 128x64), LDS-DMA 5-stage ring (the whole 160 KB LDS of a CU).
 //
 // Measured on MI355X (profiles/r01_pmc_gemm_l2_fetch.json): with 128x128x64 tiles the main loop is bound by the rate
 // at which a CU can fill LDS (~35-50 GB/s per CU, L2 hit 70-82 %), i.e. by bytes staged per FLOP (1 B / 64 FLOP).
@@ -15,8 +15,6 @@
 static __device__ __attribute__((aligned(256))) char g_zero_page256[256];
 constexpr int NS256 = 5;    // ring depth: 5 x 32 KB = the whole 160 KB LDS of a CU
 
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
 
 DEVFN int rm32_off(int row, int slot) { return row * 64 + ((slot ^ (((row >> 3) & 1) << 1)) << 4); }
 template <int BX> DEVFN int km32_off(int krow, int col) {
@@ -76,16 +74,6 @@ struct Dma32 {
       glds16_asm(src, __builtin_amdgcn_readfirstlane(lds_addr(img + (i * NT + wave * 64) * 16)));
     }
   }
-  // Pull the K-slice `kt` into this XCD's L2 ahead of time: a 4-byte LDS-DMA per unit into a per-wave scratch
-  // (no VGPR destination, so nothing to protect; it only occupies a vmcnt slot, the count per stage stays constant).
-  DEVFN void prefetch(int64_t kt, int64_t K, char* scratch, int wave) const {
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      const bool ok = okx[i] && (kt * 32 + kofs[i] < K);
-      const char* src = ok ? ptr[i] + kt * kstep : (const char*)g_zero_page256;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(scratch + wave * 256), 4, 0, 0);
-    }
-  }
 };
 
 template <typename OT, bool AKM, bool BKM, int PF>
@@ -93,8 +81,7 @@ DEVFN void dma_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char
   constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NS = NS256, NT = 512;
   constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;     // 8 x 4 accumulator tiles per wave
   constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;
-  constexpr int NPA = A_BYTES / (NT * 16), NPB = B_BYTES / (NT * 16), LPS = (NPA + NPB) * (PF > 0 ? 2 : 1);
-  char* scratch = smem;   // (prefetch experiment only; unused when PF == 0)
+  constexpr int NPA = A_BYTES / (NT * 16), NPB = B_BYTES / (NT * 16), LPS = NPA + NPB;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -121,42 +108,32 @@ DEVFN void dma_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char
   for (int s = 0; s < NS - 1; ++s) {
     ua.issue(s, p.K, smem + s * STAGE, wave);
     ub.issue(s, p.K, smem + s * STAGE + A_BYTES, wave);
-    if (PF > 0) { ua.prefetch(s + PF, p.K, scratch, wave); ub.prefetch(s + PF, p.K, scratch, wave); }
   }
   int slot = 0, fill = NS - 1;
   for (int64_t t = 0; t < nkt; ++t) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPS) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    // PF < 0: -1 / -2 are timing-only ablations (wrong results): -1 = no DMA inside the loop, -2 = no LDS reads / MFMA;
-    // -3 / -4 are schedule experiments (correct results): the wm==1 waves issue their DMA after the MFMAs (-4: + setprio)
-    const bool late = (PF == -3 || PF == -4) && wm == 1;
+    // PF = -1 / -2 are timing-only ablations (wrong results): -1 = no DMA inside the loop, -2 = no LDS reads / MFMA
     if (PF == -1) {
       ua.issue(1 << 20, p.K, smem + fill * STAGE, wave);      // zero-page DMAs keep the vmcnt bookkeeping identical
       ub.issue(1 << 20, p.K, smem + fill * STAGE + A_BYTES, wave);
-    } else if (!late) {
+    } else {
       ua.issue(t + NS - 1, p.K, smem + fill * STAGE, wave);
       ub.issue(t + NS - 1, p.K, smem + fill * STAGE + A_BYTES, wave);
     }
-    if (PF > 0) { ua.prefetch(t + NS - 1 + PF, p.K, scratch, wave); ub.prefetch(t + NS - 1 + PF, p.K, scratch, wave); }
     const char* cA = smem + slot * STAGE;
     const char* cB = cA + A_BYTES;
     if (PF != -2) {
       bf16x8 fb[NI];
 #pragma unroll
       for (int j = 0; j < NI; ++j) fb[j] = frag32<BN, BKM>(cB, wn * WTN + j * 16, lane);
-      if (PF == -4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const bf16x8 fa = frag32<BM, AKM>(cA, wm * WTM + i * 16, lane);
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = mfma_bf16_k32(fb[j], fa, acc[i][j]);
       }
-      if (PF == -4) __builtin_amdgcn_s_setprio(0);
-    }
-    if (late) {
-      ua.issue(t + NS - 1, p.K, smem + fill * STAGE, wave);
-      ub.issue(t + NS - 1, p.K, smem + fill * STAGE + A_BYTES, wave);
     }
     slot = (slot + 1 == NS) ? 0 : slot + 1;
     fill = (fill + 1 == NS) ? 0 : fill + 1;
@@ -304,23 +281,19 @@ __global__ __launch_bounds__(512) void gemm_dma256_grouped_kernel(const gstvd_ge
   dma_tile256<OT, AKM, BKM, PF>(p, 0, gid - tile_off[lo], ntn, ntm * ntn, smem);
 }
 
-constexpr int LDS256 = NS256 * (256 + 256) * 64 + (NS256 < 5 ? 8 * 256 : 0);     // ring + per-wave prefetch scratch
-constexpr int PFD = 10;                                     // prefetch distance in 32-deep K steps
-static int pf_enabled() { static const int v = [] { const char* e = getenv("GSTVD_GEMM_PF"); return e ? atoi(e) : 0; }(); return v; }
+constexpr int LDS256 = NS256 * (256 + 256) * 64;           // the ring is the whole LDS of a CU
 
 template <typename OT, bool AKM, bool BKM>
 static int launch256(const GemmP& p, int64_t batch, hipStream_t s) {
   auto k0 = gemm_dma256_kernel<OT, AKM, BKM, 0>;
   auto ka = gemm_dma256_kernel<OT, AKM, BKM, -1>;
   auto kb = gemm_dma256_kernel<OT, AKM, BKM, -2>;
-  auto kc = gemm_dma256_kernel<OT, AKM, BKM, -3>;
-  auto kd = gemm_dma256_kernel<OT, AKM, BKM, -4>;
   auto ke = gemm_dma256_kernel<OT, AKM, BKM, -5>;
-  static int attr_rc = ensure_lds(k0, LDS256) | ensure_lds(ka, LDS256) | ensure_lds(kb, LDS256) | ensure_lds(kc, LDS256) | ensure_lds(kd, LDS256) | ensure_lds(ke, LDS256);
+  static int attr_rc = ensure_lds(k0, LDS256) | ensure_lds(ka, LDS256) | ensure_lds(kb, LDS256) | ensure_lds(ke, LDS256);
   if (attr_rc) return attr_rc;
   static const int abl = [] { const char* e = getenv("GSTVD_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
   const int ntm = (int)((p.M + 255) / 256), ntn = (int)((p.N + 255) / 256);
-  hipLaunchKernelGGL(abl == 1 ? ka : abl == 2 ? kb : abl == 3 ? kc : abl == 4 ? kd : abl == 5 ? ke : k0, dim3((unsigned)(ntm * ntn), (unsigned)batch), dim3(512), LDS256, s, p, ntn, ntm * ntn);
+  hipLaunchKernelGGL(abl == 1 ? ka : abl == 2 ? kb : abl == 5 ? ke : k0, dim3((unsigned)(ntm * ntn), (unsigned)batch), dim3(512), LDS256, s, p, ntn, ntm * ntn);
   GSTVD_LAUNCH_CHECK();
   return 0;
 }
