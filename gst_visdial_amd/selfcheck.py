@@ -1,5 +1,5 @@
-"""smoke(): one tiny forward+backward of the hot path on cuda:0, checked against the CPU oracle
-(the oracle is imported here ONLY as the checker; see oracle/vd_oracle.py header)."""
+"""Fixture helpers shared by tests/ and __graft_entry__.smoke(): the tiny-config model of tests/golden/ and its
+batch.  Nothing here (or anywhere in this package) imports oracle/ -- the checking itself lives with the callers."""
 import json
 import os
 import tempfile
@@ -43,25 +43,3 @@ def golden_batch(g, device, dec_key="in::dec_input_ids", with_labels=True):
               enc_attention_mask=b["enc_attention_mask"], dec_input_ids=g[dec_key].clone().to(device),
               dec_attention_mask=b["dec_attention_mask"], dec_labels=b["dec_labels"] if with_labels else None)
     return kw
-
-
-def smoke_check():
-    from oracle import vd_oracle as O      # checker only
-    if not torch.cuda.is_available():
-        raise RuntimeError("smoke() needs cuda:0 (MI355X)")
-    model, params, cfg = build_tiny_model("fp32", "cuda:0")
-    model.eval()
-    g = load_npz("tiny_train.npz")
-    kw = golden_batch(g, "cuda:0")
-    loss, logits = model(**kw)
-    loss.backward()
-    torch.cuda.synchronize()
-    sd = load_npz("tiny_state.npz")
-    cpu_b = {k[4:]: v.clone() for k, v in g.items() if k.startswith("in::")}
-    ref = O.model_forward(sd, cfg["enc"], cfg["dec"], cpu_b)
-    err = (logits.float().cpu() - ref["logits"]).abs().max().item()
-    lerr = abs(loss.item() - ref["loss"].item())
-    gw = model.vlfusion.fc_v.weight.grad
-    assert gw is not None and torch.isfinite(gw).all()
-    assert err < 1e-4 and lerr < 1e-5, "smoke parity failed: logits err %.3e loss err %.3e" % (err, lerr)
-    print("smoke ok: logits max err %.2e, loss err %.2e (fp32 mode vs oracle)" % (err, lerr))

@@ -196,3 +196,15 @@ def test_checkpoint_round_trip_reference_layout(tiny_state, tmp_path):
     assert torch.equal(m3.vlfusion.fc_l.weight, before)
     assert torch.equal(m3.encoder.bert_pretrained.bert.encoder.layer[0].attention.self.query.weight,
                        tiny_state["encoder.bert_pretrained.bert.encoder.layer.0.attention.self.query.weight"])
+
+
+def test_product_package_never_imports_oracle():
+    """oracle/ is test infrastructure: no module of the shipped package may import it (only tests/, smoke(), bench's
+    cpu_baseline leg do)."""
+    import re
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gst_visdial_amd")
+    pat = re.compile(r"^\s*(from\s+oracle|import\s+oracle|from\s+\.+\s*oracle)", re.M)
+    for fn in sorted(os.listdir(pkg)):
+        if fn.endswith(".py"):
+            with open(os.path.join(pkg, fn)) as f:
+                assert not pat.search(f.read()), fn

@@ -312,3 +312,43 @@ def test_two_stream_schedule_matches_single_stream():
     for a, b in zip(l0, l1):
         assert abs(a - b) < 1e-5 * max(1.0, abs(a)), (l0, l1)
     assert maxerr(p0, p1) < 1e-6
+
+
+def test_step_forward_row_sampling_matches_oracle_on_selected_rows():
+    """train_gen.forward drop-in (gst_visdial_amd/step.py) on a [dialogs, rounds, 1, L] batch in which some rounds carry
+    all-zero labels (the -select_data / perplexity-filtered case of cc12m self-training): the sampled row indices are
+    the reference's (host multinomial over the non-empty rows), and the loss equals the oracle's on exactly those rows."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import vd_oracle as O
+    from gst_visdial_amd import step
+    s = sc()
+    model, params, cfg = s.build_tiny_model("fp32", DEV)
+    model.eval()
+    g = load_npz("tiny_train.npz")
+    b = {k[4:]: v.clone() for k, v in g.items() if k.startswith("in::")}
+    nb = b["enc_input_ids"].shape[0]                       # 3 golden rows -> 2 dialogs x 3 rounds (rows repeated / permuted)
+    order = torch.tensor([0, 1, 2, 2, 0, 1])
+    def dlg(x):
+        return x[order].reshape((2, 3, 1) + tuple(x.shape[1:]))
+    batch = dict(enc_input_ids=dlg(b["enc_input_ids"]), enc_segments=dlg(b["enc_segments"]), enc_att_mask=dlg(b["enc_attention_mask"]),
+                 dec_input_ids=dlg(b["dec_input_ids"]), dec_att_mask=dlg(b["dec_attention_mask"]), dec_labels=dlg(b["dec_labels"]),
+                 enc_image_feat=dlg(b["enc_image_features"]), enc_image_loc=dlg(b["enc_image_spatials"]),
+                 enc_image_mask=dlg(b["enc_image_mask"]))
+    batch["dec_labels"][0, 1] = 0                          # filtered-out rounds: never sampled
+    batch["dec_labels"][1, 0] = 0
+    p = dict(params, mode="vd_train", batch_size=5, device=torch.device(DEV))
+    gen = torch.Generator().manual_seed(123)
+    loss, scores = step.forward(model, batch, p, generator=gen)
+    # reference semantics restated by the oracle: candidates = rows with a non-zero label row, multinomial with replacement
+    flat_labels = batch["dec_labels"].reshape(-1, batch["dec_labels"].shape[-1])
+    cand = O.candidate_rows(flat_labels)
+    idx = torch.multinomial(cand, 5, replacement=True, generator=torch.Generator().manual_seed(123))
+    assert not set(idx.tolist()) & {1, 3}
+    rows = O.flatten_and_gather(batch, idx)
+    ob = dict(enc_image_features=rows["enc_image_feat"], enc_image_spatials=rows["enc_image_loc"], enc_image_mask=rows["enc_image_mask"],
+              enc_input_ids=rows["enc_input_ids"], enc_segments=rows["enc_segments"], enc_attention_mask=rows["enc_att_mask"],
+              dec_input_ids=rows["dec_input_ids"], dec_attention_mask=rows["dec_att_mask"], dec_labels=rows["dec_labels"])
+    ref = O.model_forward(load_npz("tiny_state.npz"), cfg["enc"], cfg["dec"], ob)
+    assert abs(loss.item() - ref["loss"].item()) < 1e-5
+    assert maxerr(scores, ref["logits"]) < 1e-4
