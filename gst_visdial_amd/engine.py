@@ -282,6 +282,7 @@ class Engine(object):
         self.flat = None
         self.arena = None
         self.rng = None
+        self._decode_sessions = {}
         self.anchor = None
         self.grad_hook = None          # callable(offset): every gradient at flat offset >= `offset` is final
         self.pipe = None               # BackwardPipeline (pipeline.py): slice-wise wgrad / all-reduce / AdamW on the aux stream
@@ -855,36 +856,38 @@ class Engine(object):
         return scores
 
     # ------------------------------------------------------------------------------------------ sampling decode
-    @torch.no_grad()
-    def sample(self, feats, loc, img_mask, ids, segs, att_mask, dec_ids, temperature=1.0, top_k=0, top_p=0.0,
-               ngram_blocking_size=0, max_seq_len=18, **_):
-        """models/visual_dialog_model.py:74-120: 18 sampling steps (temperature, n-gram blocking, top-k / top-p, multinomial
-        draw, [PAD] after the first [SEP]).  The reference re-runs the whole decoder on the growing prefix and re-projects
-        the cross-attention K/V of all 37+T encoder states in all 12 layers at every step (use_cache=False); here the
-        encoder, VLFusion and the cross K/V projection run once, and each step feeds ONE token per row through the stack,
-        appending its self-attention K/V to a [B, Umax, H] cache per layer.  Same arithmetic, O(U) instead of O(U^2).
-        Token-id work (filters, n-gram ban, EOS fill) is integer-exact torch / host plumbing (decoding.py)."""
-        from . import decoding
-        self._begin(ids.device, False)
-        self.train = False
+    def _decode_plan(self, ins, L0, max_seq_len):
+        """Builds the two device programs of a decode call on the engine's arena: `encode()` (encoder, VLFusion, the
+        cross-attention K/V of all decoder layers -- once per call) and `one_token(tok, t)` (ONE token per row through
+        the decoder stack at position t, its self-attention K/V appended to the per-layer caches) -> fp32 logits [B, V].
+        `ins` = (feats, loc, img_mask, ids, segs, att_mask, dec_ids) are the tensors the kernels read."""
+        feats, loc, img_mask, ids, segs, att_mask, dec_ids = ins
         dc = self.dec_cfg
-        I = self._inputs(feats, loc, img_mask, ids, segs, att_mask, dec_ids, None)
-        xt, xv = self.encoder(I)
-        enc = self.fusion(xt, xv, I)
-        Bn, V, Vp = I["B"], dc.vocab_size, self.flat.Vp
-        L, H, nh = dc.num_hidden_layers, dc.hidden_size, dc.num_attention_heads
-        d, S, eps = H // nh, I["R"] + I["T"], dc.layer_norm_eps
-        kv = self.lin(enc, "dec.ckv.w", "dec.ckv.b", 2 * L * H, H)      # cross K/V of all layers, once
-        L0 = dec_ids.shape[1]
-        Umax = L0 + max_seq_len
-        Kc = [Act(self.buf(Bn * Umax, H), Bn * Umax, H) for _ in range(L)]
-        Vc = [Act(self.buf(Bn * Umax, H), Bn * Umax, H) for _ in range(L)]
-        prefix = "emb" if self.flat.dec_emb is self.flat.enc_emb else "demb"
-        mark = self.arena.mark()
+        st = {}
+
+        def encode():
+            self._begin(ids.device, False)
+            self.train = False
+            I = self._inputs(feats, loc, img_mask, ids, segs, att_mask, dec_ids, None)
+            xt, xv = self.encoder(I)
+            enc = self.fusion(xt, xv, I)
+            Bn = I["B"]
+            L, H = dc.num_hidden_layers, dc.hidden_size
+            st["I"], st["Bn"], st["S"] = I, Bn, I["R"] + I["T"]
+            st["kv"] = self.lin(enc, "dec.ckv.w", "dec.ckv.b", 2 * L * H, H)      # cross K/V of all layers, once
+            Umax = L0 + max_seq_len
+            st["Umax"] = Umax
+            st["Kc"] = [Act(self.buf(Bn * Umax, H), Bn * Umax, H) for _ in range(L)]
+            st["Vc"] = [Act(self.buf(Bn * Umax, H), Bn * Umax, H) for _ in range(L)]
+            st["mark"] = self.arena.mark()
 
         def one_token(tok, t):
-            """logits [B, V] for the token at position t (its K/V are appended to the caches)."""
-            self.arena.rewind(mark)
+            I, Bn, S, kv, Kc, Vc, Umax = st["I"], st["Bn"], st["S"], st["kv"], st["Kc"], st["Vc"], st["Umax"]
+            V, Vp = dc.vocab_size, self.flat.Vp
+            L, H, nh, eps = dc.num_hidden_layers, dc.hidden_size, dc.num_attention_heads, dc.layer_norm_eps
+            d = H // nh
+            prefix = "emb" if self.flat.dec_emb is self.flat.enc_emb else "demb"
+            self.arena.rewind(st["mark"])
             y = self.embed(prefix, tok.contiguous(), None, Bn, 1, dc, pos_offset=t)
             for i in range(L):
                 p = "d%d" % i
@@ -903,10 +906,68 @@ class Engine(object):
                 y = self.ln(fo, y2, p + ".ln3.w", p + ".ln3.b", H, 0.0, None, eps)
             return self.lin(y, "lm.w", "lm.b", Vp, H).t[:, :V].float()
 
+        return encode, one_token
+
+    def _decode_session(self, ins, L0, max_seq_len):
+        """hipGraph form of a decode call (generate.py's loop calls sample() with the same shapes batch after batch):
+        static copies of the inputs, one captured graph for `encode`, one per decoder position for `one_token`.
+        Returns (refresh(ins), run_encode(), run_token(tok, t) -> logits)."""
+        static = tuple(x.clone() if x is not None else None for x in ins)
+        tok_buf = torch.zeros(ins[3].shape[0], dtype=torch.long, device=ins[3].device)
+        encode, one_token = self._decode_plan(static, L0, max_seq_len)
+        torch.cuda.synchronize()
+        g_enc = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_enc):
+            encode()
+        graphs, outs = [], []
+        for t in range(L0 + max_seq_len - 1):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=g_enc.pool()):
+                outs.append(one_token(tok_buf, t))
+            graphs.append(g)
+
+        def refresh(new):
+            for dst, src in zip(static, new):
+                if dst is not None:
+                    dst.copy_(src)
+
+        def run_token(tok, t):
+            tok_buf.copy_(tok)
+            graphs[t].replay()
+            return outs[t]
+
+        return refresh, g_enc.replay, run_token
+
+    @torch.no_grad()
+    def sample(self, feats, loc, img_mask, ids, segs, att_mask, dec_ids, temperature=1.0, top_k=0, top_p=0.0,
+               ngram_blocking_size=0, max_seq_len=18, **_):
+        """models/visual_dialog_model.py:74-120: 18 sampling steps (temperature, n-gram blocking, top-k / top-p, multinomial
+        draw, [PAD] after the first [SEP]).  The reference re-runs the whole decoder on the growing prefix and re-projects
+        the cross-attention K/V of all 37+T encoder states in all 12 layers at every step (use_cache=False); here the
+        encoder, VLFusion and the cross K/V projection run once, and each step feeds ONE token per row through the stack,
+        appending its self-attention K/V to a [B, Umax, H] cache per layer.  Same arithmetic, O(U) instead of O(U^2).
+        From the second call with the same shapes on (params['amd_decode_graph'], default on) the device work is replayed
+        from captured hipGraphs (one for the encoder side, one per decoder position): ~2500 launches per call leave the host.
+        Token-id work (filters, n-gram ban, EOS fill) is integer-exact torch / host plumbing (decoding.py)."""
+        from . import decoding
+        dc = self.dec_cfg
+        if segs is None:
+            segs = torch.zeros_like(ids)
+        ins = (feats, loc, img_mask, ids, segs, att_mask, dec_ids)
+        L0 = dec_ids.shape[1]
+        sig = (L0, max_seq_len) + tuple((tuple(x.shape), x.dtype) if x is not None else None for x in ins)
+        use_graph = bool(self.model.params.get("amd_decode_graph", True))
+        sess = self._decode_sessions.get(sig) if use_graph else None
+        if sess is not None:
+            refresh, run_encode, run_token = sess
+            refresh(ins)
+        else:
+            run_encode, run_token = self._decode_plan(ins, L0, max_seq_len)
+        run_encode()
         hist = ids * (segs == 0).long()
         cur, seq = dec_ids, []
-        for t in range(Umax - 1):
-            logits = one_token(cur[:, t], t)
+        for t in range(L0 + max_seq_len - 1):
+            logits = run_token(cur[:, t], t)
             if t < L0 - 1:
                 continue                                   # still consuming the given prefix
             last = logits / temperature
@@ -915,7 +976,15 @@ class Engine(object):
             nxt = torch.multinomial(torch.softmax(last, dim=-1), 1)
             cur = torch.cat((cur, nxt), dim=-1)
             seq.append(nxt)
-        return decoding.pad_after_eos(torch.cat(seq, 1), dc.eos_token_id, dc.pad_token_id)
+        self.last = dict(decode_logits=logits)            # last position's raw logits (tests / debugging)
+        out = decoding.pad_after_eos(torch.cat(seq, 1), dc.eos_token_id, dc.pad_token_id)
+        if use_graph and sess is None:
+            # first call with these shapes ran eagerly (it also initialised every lazily built table / attribute / arena
+            # chunk); capture now so the next batch replays
+            if len(self._decode_sessions) >= 4:
+                self._decode_sessions.clear()
+            self._decode_sessions[sig] = self._decode_session(ins, L0, max_seq_len)
+        return out
 
 
 class _StepFn(torch.autograd.Function):

@@ -170,6 +170,52 @@ def test_sampling_decode_matches_reference_argmax_path(monkeypatch):
     assert torch.equal(seq.cpu(), d["sequence"])
 
 
+def test_graph_captured_decode_equals_eager_decode(monkeypatch):
+    """generate.py calls the decode branch batch after batch with the same shapes: from the second call on the device
+    work is replayed from hipGraphs (encoder side + one graph per decoder position).  Same token ids as the eager path,
+    also for new inputs copied into the captured buffers, and still the reference's golden sequence."""
+    s = sc()
+    g, d = load_npz("tiny_train.npz"), load_npz("tiny_decode.npz")
+    monkeypatch.setattr(torch, "multinomial", lambda prob, n, **kw: prob.argmax(-1, keepdim=True))
+
+    def batch(shift):
+        kw = s.golden_batch(g, DEV)
+        kw["dec_input_ids"] = torch.full((kw["enc_input_ids"].shape[0], 1), 101, dtype=torch.long, device=DEV)
+        kw["dec_labels"] = None
+        if shift:                                              # a different dialog: other tokens, other features
+            ids = kw["enc_input_ids"]
+            kw["enc_input_ids"] = torch.where(ids > 110, (ids - 111 + shift) % 200 + 111, ids)
+            kw["enc_image_features"] = kw["enc_image_features"].flip(0).contiguous()
+        return kw
+
+    args = dict(temperature=0.7, top_k=7, top_p=0.0, ngram_blocking_size=2)
+    model, params, cfg = s.build_tiny_model("fp32", DEV, mode="vd_gen_val")
+    model.eval()
+    a0 = model(**args, **batch(0))                             # eager, then captures
+    assert len(model.engine._decode_sessions) == 1
+    a1 = model(**args, **batch(0))                             # replay
+    assert torch.equal(a0.cpu(), d["sequence"]) and torch.equal(a1, a0)
+    # real multinomial draws at high temperature: the drawn ids follow the probabilities to the last bit, so equality with
+    # the eager engine needs bit-identical logits at every step, and different inputs give different sequences
+    monkeypatch.undo()
+    hot = dict(temperature=2.0, top_k=60, top_p=0.0, ngram_blocking_size=0)
+    ref, rparams, _ = s.build_tiny_model("fp32", DEV, mode="vd_gen_val")
+    rparams["amd_decode_graph"] = False
+    ref.eval()
+    outs = []
+    for shift in (0, 17):
+        torch.manual_seed(99)
+        a = model(**hot, **batch(shift))                       # replay (same shapes as the captured session)
+        torch.manual_seed(99)
+        r = ref(**hot, **batch(shift))                         # eager engine
+        assert torch.equal(a, r)
+        la, lr = model.engine.last["decode_logits"].clone(), ref.engine.last["decode_logits"].clone()
+        assert torch.equal(la, lr)                             # bit-identical logits from the replayed graphs
+        outs.append(la)
+    assert len(model.engine._decode_sessions) == 1 and len(ref.engine._decode_sessions) == 0
+    assert not torch.equal(outs[0], outs[1])                   # ... and they do follow the refreshed inputs
+
+
 def test_smoke_entry_point():
     import __graft_entry__ as ge
     ge.smoke()
