@@ -12,7 +12,9 @@ struct LnP {
   float *dword, *dpos, *dtt, *dtt_ext;
 };
 
-constexpr int LN_BWD_RPB = 8;    // rows per block in backward (4 waves x 2 rows)
+// rows per wave in backward: 2 (both rows' loads in flight before any reduction) for large M; 1 for small M, where the
+// grid cannot fill the chip anyway and the shorter per-wave chain is what counts (decoder / vision rows)
+static inline int ln_bwd_rw(int64_t M) { return M <= 8192 ? 1 : 2; }
 
 // h = pre-LayerNorm row, 4 elements starting at column c
 template <typename T, int MODE>
@@ -93,11 +95,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(gstvd_ln_t f) {
   }
 }
 
-// Backward: a block owns LN_BWD_RPB = 8 consecutive rows, each wave two of them.  Both rows' loads are issued
+// Backward: a block owns 4*RW consecutive rows, each wave RW of them (RW = 1 up to 8192 rows: measured 17.1 -> 13.0 us
+// at 4096x768 and 13.4 -> 8.0 us at 400x768; RW = 2 beyond).  With RW = 2 both rows' loads are issued
 // before any reduction (memory-level parallelism), column partial sums stay in registers and are combined
 // across the 4 waves through LDS with plain stores (no LDS atomics), one [3][H] slab per block goes to HBM.
-template <typename T, int MODE, int NV>
+template <typename T, int MODE, int NV, int RW>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(LnP p) {
+  constexpr int LN_BWD_RPB = 4 * RW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* red = (float*)smem;                   // [4 waves][3][H]
   const gstvd_ln_t& f = p.f;
@@ -110,13 +114,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnP p) {
 #pragma unroll
   for (int i = 0; i < NV; ++i) ag[i] = ab[i] = ax[i] = a4[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int64_t row0 = (int64_t)blockIdx.x * LN_BWD_RPB + wave * 2;
-  f32x4 xh[2][NV], gy[2][NV], dyv[2][NV];
-  float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f}, rstd[2] = {0.f, 0.f};
-  int64_t id[2] = {0, 0}, tpos[2] = {0, 0}, seg[2] = {0, 0};
-  bool rv[2];
+  const int64_t row0 = (int64_t)blockIdx.x * LN_BWD_RPB + wave * RW;
+  f32x4 xh[RW][NV], gy[RW][NV], dyv[RW][NV];
+  float s1[RW] = {}, s2[RW] = {}, rstd[RW] = {};
+  int64_t id[RW] = {}, tpos[RW] = {}, seg[RW] = {};
+  bool rv[RW];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < RW; ++j) {
     const int64_t row = row0 + j;
     rv[j] = row < f.M;
     float locrow[5] = {0, 0, 0, 0, 0};
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnP p) {
     }
   }
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < RW; ++j) {
     const int64_t row = row0 + j;
     const float c1 = wave_sum(s1[j]) / (float)H, c2 = wave_sum(s2[j]) / (float)H;
 #pragma unroll
@@ -374,28 +378,32 @@ extern "C" int gstvd_ln_fwd(const gstvd_ln_t* p, gstvd_stream_t stream) {
   return p->dtype == GSTVD_BF16 ? ln_fwd_mode<bf16>(*p, s) : ln_fwd_mode<float>(*p, s);
 }
 
-extern "C" int64_t gstvd_ln_bwd_blocks(int64_t M) { return (M + LN_BWD_RPB - 1) / LN_BWD_RPB; }
+extern "C" int64_t gstvd_ln_bwd_blocks(int64_t M) { const int rpb = 4 * ln_bwd_rw(M); return (M + rpb - 1) / rpb; }
 
-template <typename T, int MODE>
+template <typename T, int MODE, int RW>
 static int ln_bwd_nv(const LnP& p, hipStream_t s) {
   dim3 grid((unsigned)gstvd_ln_bwd_blocks(p.f.M)), block(256);
   size_t lds = (size_t)4 * (MODE == GSTVD_LN_EMBED ? 4 : 3) * p.f.H * sizeof(float);
   if (lds > 48 * 1024) {
-    static int rc8 = (int)hipFuncSetAttribute((const void*)ln_bwd_kernel<T, MODE, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4 * 2048 * 4);
+    static int rc8 = (int)hipFuncSetAttribute((const void*)ln_bwd_kernel<T, MODE, 8, RW>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4 * 2048 * 4);
     if (rc8) return rc8;
   }
-  if (p.f.H <= 256) hipLaunchKernelGGL((ln_bwd_kernel<T, MODE, 1>), grid, block, lds, s, p);
-  else if (p.f.H <= 768) hipLaunchKernelGGL((ln_bwd_kernel<T, MODE, 3>), grid, block, lds, s, p);
-  else if (p.f.H <= 1024) hipLaunchKernelGGL((ln_bwd_kernel<T, MODE, 4>), grid, block, lds, s, p);
-  else hipLaunchKernelGGL((ln_bwd_kernel<T, MODE, 8>), grid, block, lds, s, p);
+  if (p.f.H <= 256) hipLaunchKernelGGL((ln_bwd_kernel<T, MODE, 1, RW>), grid, block, lds, s, p);
+  else if (p.f.H <= 768) hipLaunchKernelGGL((ln_bwd_kernel<T, MODE, 3, RW>), grid, block, lds, s, p);
+  else if (p.f.H <= 1024) hipLaunchKernelGGL((ln_bwd_kernel<T, MODE, 4, RW>), grid, block, lds, s, p);
+  else hipLaunchKernelGGL((ln_bwd_kernel<T, MODE, 8, RW>), grid, block, lds, s, p);
   GSTVD_LAUNCH_CHECK();
   return 0;
 }
+template <typename T, int MODE>
+static int ln_bwd_rows(const LnP& p, hipStream_t s) {
+  return ln_bwd_rw(p.f.M) == 1 ? ln_bwd_nv<T, MODE, 1>(p, s) : ln_bwd_nv<T, MODE, 2>(p, s);
+}
 template <typename T>
 static int ln_bwd_mode(const LnP& p, hipStream_t s) {
-  if (p.f.mode == GSTVD_LN_RESID) return ln_bwd_nv<T, GSTVD_LN_RESID>(p, s);
-  if (p.f.mode == GSTVD_LN_EMBED) return ln_bwd_nv<T, GSTVD_LN_EMBED>(p, s);
-  return ln_bwd_nv<T, GSTVD_LN_IMAGE>(p, s);
+  if (p.f.mode == GSTVD_LN_RESID) return ln_bwd_rows<T, GSTVD_LN_RESID>(p, s);
+  if (p.f.mode == GSTVD_LN_EMBED) return ln_bwd_rows<T, GSTVD_LN_EMBED>(p, s);
+  return ln_bwd_rows<T, GSTVD_LN_IMAGE>(p, s);
 }
 extern "C" int gstvd_ln_bwd(const gstvd_ln_bwd_t* b, gstvd_stream_t stream) {
   if (!b) return GSTVD_E_NULL;
