@@ -27,6 +27,13 @@ DEVFN f32x4 ld4(const bf16* p) {
   f32x4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
   return r;
 }
+// streaming (non-temporal) variants for data that is read exactly once
+DEVFN f32x4 ld4_stream(const float* p) { return __builtin_nontemporal_load((const f32x4*)p); }
+DEVFN f32x4 ld4_stream(const bf16* p) {
+  bf16x4 v = __builtin_nontemporal_load((const bf16x4*)p);
+  f32x4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  return r;
+}
 DEVFN void st4(float* p, f32x4 v) { *(f32x4*)p = v; }
 DEVFN void st4(bf16* p, f32x4 v) {
   bf16x4 r = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};

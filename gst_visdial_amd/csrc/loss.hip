@@ -128,28 +128,43 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* param, const GT* grad
                                                     const int64_t* seg_end, const float* hp, int64_t nseg, float b1, float b2,
                                                     float eps, const float* step, float gscale, int64_t base, int64_t gorigin) {
   // the launch covers flat elements [base, n) of the buffers (pointers are the buffers' starts); segment ends are absolute
-  const int64_t i = base + ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  __shared__ float s_bc;
+  const int64_t i0 = base + (int64_t)blockIdx.x * 1024;           // block-uniform: the search below runs on scalar loads
+  const int64_t i = i0 + threadIdx.x * 4;
+  if (threadIdx.x == 0) {
+    const float t = step[0];
+    s_bc = sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));         // bias correction, once per block
+  }
+  // streaming operands first (their latency overlaps the segment lookup); nothing here is re-read, keep it out of L2's way
+  const bool vec = i + 3 < n;
+  f32x4 g4 = {0.f, 0.f, 0.f, 0.f}, m4 = g4, v4 = g4, p4 = g4;
+  if (vec) {
+    g4 = ld4_stream(grad + (i - gorigin));
+    m4 = __builtin_nontemporal_load((const f32x4*)(m + i));
+    v4 = __builtin_nontemporal_load((const f32x4*)(v + i));
+    p4 = __builtin_nontemporal_load((const f32x4*)(param + i));
+  }
+  int64_t lo = 0, hi = nseg - 1;                       // first segment whose end > i0
+  while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (seg_end[mid] > i0) hi = mid; else lo = mid + 1; }
+  __syncthreads();
   if (i >= n) return;
-  int64_t lo = 0, hi = nseg - 1;                       // first segment whose end > i
-  while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (seg_end[mid] > i) hi = mid; else lo = mid + 1; }
+  while (lo < nseg - 1 && seg_end[lo] <= i) ++lo;     // at most a few steps inside a 1024-element block
   const float lr = hp[2 * lo], wd = hp[2 * lo + 1];
-  if (lr == 0.f) return;                               // padding / frozen segment
-  const float t = step[0];
-  const float bc = sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
-  if (i + 3 < n && seg_end[lo] >= i + 4) {
-    const f32x4 g4 = ld4(grad + (i - gorigin)) * gscale;
-    const f32x4 m4 = *(const f32x4*)(m + i) * b1 + g4 * (1.f - b1);
-    const f32x4 v4 = *(const f32x4*)(v + i) * b2 + g4 * g4 * (1.f - b2);
-    f32x4 p4 = *(const f32x4*)(param + i);
+  const float bc = s_bc;
+  if (vec && seg_end[lo] >= i + 4) {
+    if (lr == 0.f) return;                               // padding / frozen segment
+    g4 *= gscale;
+    m4 = m4 * b1 + g4 * (1.f - b1);
+    v4 = v4 * b2 + g4 * g4 * (1.f - b2);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float pp = p4[e] - lr * bc * (m4[e] / (sqrtf(v4[e]) + eps));
       if (wd > 0.f) pp += -lr * wd * pp;
       p4[e] = pp;
     }
-    *(f32x4*)(m + i) = m4;
-    *(f32x4*)(v + i) = v4;
-    *(f32x4*)(param + i) = p4;
+    __builtin_nontemporal_store(m4, (f32x4*)(m + i));
+    __builtin_nontemporal_store(v4, (f32x4*)(v + i));
+    __builtin_nontemporal_store(p4, (f32x4*)(param + i));
     if (shadow) st4(shadow + i, p4);
     return;
   }
