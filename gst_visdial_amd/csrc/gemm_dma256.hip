@@ -266,7 +266,10 @@ __global__ __launch_bounds__(512) void gemm_dma256_kernel(GemmP p, int ntn, int 
 template <typename OT, bool AKM, bool BKM, int PF>
 __global__ __launch_bounds__(512) void gemm_dma256_grouped_kernel(const gstvd_gemm_t* tab, const int* tile_off, int nprob, int total) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int gid = xcd_remap256(blockIdx.x, total);
+  // XCD x (blocks b with b % 8 == x) walks chunks x, x+8, x+16, ... of 32 consecutive tiles: neighbours in the table share
+  // operands (one problem ~ one chunk), and long-K and short-K problems are spread over all eight XCDs
+  const int full = total & ~255, bid = blockIdx.x;
+  const int gid = bid < full ? (((bid >> 3) >> 5) * 8 + (bid & 7)) * 32 + ((bid >> 3) & 31) : bid;
   int lo = 0, hi = nprob - 1;
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tile_off[mid] <= gid) lo = mid; else hi = mid - 1; }
   const gstvd_gemm_t& g = tab[lo];
