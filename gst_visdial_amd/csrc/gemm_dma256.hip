@@ -264,12 +264,12 @@ __global__ __launch_bounds__(512) void gemm_dma256_kernel(GemmP p, int ntn, int 
 }
 
 template <typename OT, bool AKM, bool BKM, int PF>
-__global__ __launch_bounds__(512) void gemm_dma256_grouped_kernel(const gstvd_gemm_t* tab, const int* tile_off, int nprob, int total) {
+__global__ __launch_bounds__(512) void gemm_dma256_grouped_kernel(const gstvd_gemm_t* tab, const int* tile_off, int nprob, int total, int chs) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // XCD x (blocks b with b % 8 == x) walks chunks x, x+8, x+16, ... of 32 consecutive tiles: neighbours in the table share
+  // XCD x (blocks b with b % 8 == x) walks chunks x, x+8, x+16, ... of 2^chs consecutive tiles: neighbours in the table share
   // operands (one problem ~ one chunk), and long-K and short-K problems are spread over all eight XCDs
-  const int full = total & ~255, bid = blockIdx.x;
-  const int gid = bid < full ? (((bid >> 3) >> 5) * 8 + (bid & 7)) * 32 + ((bid >> 3) & 31) : bid;
+  const int full = total - total % (8 << chs), bid = blockIdx.x;
+  const int gid = bid < full ? (((bid >> 3) >> chs) * 8 + (bid & 7)) * (1 << chs) + ((bid >> 3) & ((1 << chs) - 1)) : bid;
   int lo = 0, hi = nprob - 1;
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tile_off[mid] <= gid) lo = mid; else hi = mid - 1; }
   const gstvd_gemm_t& g = tab[lo];
@@ -324,7 +324,9 @@ static int grouped256(const gstvd_gemm_t* tab, const int* off, int nprob, int to
   auto k0 = gemm_dma256_grouped_kernel<OT, AKM, BKM, 0>;
   static int attr_rc = ensure_lds(k0, LDS256);
   if (attr_rc) return attr_rc;
-  hipLaunchKernelGGL(k0, dim3((unsigned)total), dim3(512), LDS256, s, tab, off, nprob, total);
+  // tiles per XCD chunk = 2^chs (default 8: measured best of 1..128 inside the step); GSTVD_GROUP_CHUNK_LOG2 overrides for tuning runs
+  static const int chs = [] { const char* e = getenv("GSTVD_GROUP_CHUNK_LOG2"); const int v = e ? atoi(e) : 3; return v < 0 ? 0 : (v > 10 ? 10 : v); }();
+  hipLaunchKernelGGL(k0, dim3((unsigned)total), dim3(512), LDS256, s, tab, off, nprob, total, chs);
   GSTVD_LAUNCH_CHECK();
   return 0;
 }
