@@ -111,6 +111,96 @@ DEVFN void gemm_epilogue_tile(const GemmP& p, const DropKey& dk, f32x4 acc, int6
   st4(C + m * p.ldc + n, v);
 }
 
+// ---- row-wise epilogue through LDS (bf16 outputs of the LDS-DMA kernels) ---------------------------------------------
+// In the MFMA layout a lane owns 4 columns of 16 different rows, so every C store / addend / aux access is an 8-byte piece
+// and one wave instruction touches 16 rows.  Here a wave parks its fp32 accumulators -- HB 16-row blocks at a time -- in
+// its own slice of the (now idle) ring, reads them back with each lane owning 8 consecutive columns of ONE row, and runs
+// the whole epilogue in that layout: 16-byte accesses, full 64/128-byte row segments per instruction.  Same arithmetic
+// per element in the same order as gemm_epilogue_tile (fp32 until the final rounding), so results are bit-identical.
+// The caller guarantees (uniformly) 16-byte alignment of every operand row: see epilogue_rows_ok().
+template <int NI> constexpr int epi_row_floats() { return NI * 16 + 4; }          // +4 floats: conflict-free b128 parking
+template <int NI, int HB> constexpr int epi_wave_bytes() { return HB * 16 * epi_row_floats<NI>() * 4; }
+
+DEVFN bool epilogue_rows_ok(const GemmP& p) {
+  bool ok = (p.ldc % 8 == 0) && (p.sC % 8 == 0);
+  if (p.epi & GSTVD_EPI_ADD) ok = ok && (p.ldadd % 8 == 0) && (p.sAdd % 8 == 0) && (((uintptr_t)p.addend & 15) == 0);
+  if (p.epi & (GSTVD_EPI_GELU | GSTVD_EPI_DGELU)) ok = ok && (p.ldaux % 8 == 0) && (p.sAux % 8 == 0) && (((uintptr_t)p.aux & 15) == 0);
+  if (p.epi & GSTVD_EPI_BIAS) ok = ok && (((uintptr_t)p.bias & 15) == 0);
+  return ok;
+}
+
+DEVFN void ld8(const bf16* q, f32x4& lo, f32x4& hi) {
+  const bf16x8 v = *(const bf16x8*)q;
+  lo = (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  hi = (f32x4){(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+}
+DEVFN void st8(bf16* q, const f32x4& lo, const f32x4& hi) {
+  const bf16x8 v = {(bf16)lo[0], (bf16)lo[1], (bf16)lo[2], (bf16)lo[3], (bf16)hi[0], (bf16)hi[1], (bf16)hi[2], (bf16)hi[3]};
+  *(bf16x8*)q = v;
+}
+
+template <int MI, int NI, int HB>
+DEVFN void gemm_epilogue_rows(const GemmP& p, const DropKey& dk, const f32x4 (&acc)[MI][NI], int64_t z, int64_t mw, int64_t nw,
+                              char* lds_wave, int lane) {
+  static_assert(MI % HB == 0, "row blocks per pass must divide the wave tile");
+  constexpr int S = epi_row_floats<NI>(), LPR = NI * 2, RPI = 64 / LPR, ROWS = HB * 16;
+  const int g = lane >> 4, li = lane & 15;
+  const int rl = lane / LPR, c8 = (lane % LPR) * 8;
+  float* park = (float*)lds_wave;
+  bf16* C = (bf16*)p.C + z * p.sC;
+  const int64_t n = nw + c8;
+  const bool n_lo = n < p.N, n_hi = n + 4 < p.N;                 // N % 4 == 0: a 4-column half is all in or all out
+  f32x4 b_lo = {0.f, 0.f, 0.f, 0.f}, b_hi = b_lo;
+  if (p.epi & GSTVD_EPI_BIAS) {
+    if (n_lo) b_lo = *(const f32x4*)(p.bias + n);
+    if (n_hi) b_hi = *(const f32x4*)(p.bias + n + 4);
+  }
+#pragma unroll
+  for (int pb = 0; pb < MI / HB; ++pb) {
+#pragma unroll
+    for (int i = 0; i < HB; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) *(f32x4*)(park + (i * 16 + li) * S + j * 16 + 4 * g) = acc[pb * HB + i][j];
+#pragma unroll
+    for (int rr = 0; rr < ROWS / RPI; ++rr) {
+      const int row = rr * RPI + rl;
+      const int64_t m = mw + pb * ROWS + row;
+      f32x4 lo = *(const f32x4*)(park + row * S + c8), hi = *(const f32x4*)(park + row * S + c8 + 4);
+      if (m >= p.M || !n_lo) continue;
+      lo = lo * p.alpha + b_lo;
+      hi = hi * p.alpha + b_hi;
+      const bool full = n_hi;
+      if (p.epi & GSTVD_EPI_ADD) {
+        const bf16* ap = (const bf16*)p.addend + z * p.sAdd + m * p.ldadd + n;
+        if (full) { f32x4 a0, a1; ld8(ap, a0, a1); lo += a0; hi += a1; }
+        else lo += ld4(ap);
+      }
+      if (p.epi & GSTVD_EPI_GELU) {
+        f32x4 d0, d1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float g_, d_;
+          gelu_both<true>(lo[e], g_, d_); lo[e] = g_; d0[e] = d_;
+          gelu_both<true>(hi[e], g_, d_); hi[e] = g_; d1[e] = d_;
+        }
+        bf16* xp = (bf16*)p.aux + z * p.sAux + m * p.ldaux + n;
+        if (full) st8(xp, d0, d1); else st4(xp, d0);
+      }
+      if (p.epi & GSTVD_EPI_DGELU) {
+        const bf16* xp = (const bf16*)p.aux + z * p.sAux + m * p.ldaux + n;
+        if (full) { f32x4 a0, a1; ld8(xp, a0, a1); lo *= a0; hi *= a1; }
+        else lo *= ld4(xp);
+      }
+      if (dk.on) {
+        const uint64_t e0 = (uint64_t)((z * p.M + m) * p.N + n);
+        lo *= drop_factor4(dk, e0);
+        if (full) hi *= drop_factor4(dk, e0 + 4);
+      }
+      if (full) st8(C + m * p.ldc + n, lo, hi); else st4(C + m * p.ldc + n, lo);
+    }
+  }
+}
+
 template <typename K> static int ensure_lds(K kernel, int bytes) {
   if (bytes <= 48 * 1024) return 0;
   hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);

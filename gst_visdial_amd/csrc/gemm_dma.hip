@@ -169,6 +169,15 @@ DEVFN void dma_tile(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char* s
 
   const int g = lane >> 4, li = lane & 15;
   const DropKey dk = make_drop((p.epi & GSTVD_EPI_DROPOUT) ? p.p : 0.f, p.site, p.rng);
+  if constexpr (sizeof(OT) == 2) {
+    if (epilogue_rows_ok(p)) {
+      constexpr int HB = MI < 4 ? MI : 4;
+      static_assert(WM * WN * epi_wave_bytes<NI, HB>() <= NS * STAGE, "epilogue parking must fit in the ring");
+      __builtin_amdgcn_s_barrier();            // every wave is done reading the ring: its LDS is free for the row-wise epilogue
+      gemm_epilogue_rows<MI, NI, HB>(p, dk, acc, z, m0 + wm * WTM, n0 + wn * WTN, smem + wave * epi_wave_bytes<NI, HB>(), lane);
+      return;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
