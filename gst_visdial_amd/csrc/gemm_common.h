@@ -155,8 +155,28 @@ DEVFN void gemm_epilogue_rows(const GemmP& p, const DropKey& dk, const f32x4 (&a
     if (n_lo) b_lo = *(const f32x4*)(p.bias + n);
     if (n_hi) b_hi = *(const f32x4*)(p.bias + n + 4);
   }
+  // the pass's addend (or, without an addend, aux) rows are fetched up front -- one 16-byte load per row in flight per lane
+  // while the accumulators make their LDS round trip -- instead of one exposed load latency per row
+  const bool pre_add = (p.epi & GSTVD_EPI_ADD) != 0, pre_aux = !pre_add && (p.epi & GSTVD_EPI_DGELU);
+  const bf16* pre_base = pre_add ? (const bf16*)p.addend + z * p.sAdd : (const bf16*)p.aux + z * p.sAux;
+  const int64_t pre_ld = pre_add ? p.ldadd : p.ldaux;
 #pragma unroll
   for (int pb = 0; pb < MI / HB; ++pb) {
+    bf16x8 pre[ROWS / RPI];
+    if (pre_add || pre_aux) {
+#pragma unroll
+      for (int rr = 0; rr < ROWS / RPI; ++rr) {
+        const int64_t m = mw + pb * ROWS + rr * RPI + rl;
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const s16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+        pre[rr] = __builtin_bit_cast(bf16x8, zero);
+        if (m < p.M && n_hi) pre[rr] = *(const bf16x8*)(pre_base + m * pre_ld + n);
+        else if (m < p.M && n_lo) {
+          const bf16x4 h = *(const bf16x4*)(pre_base + m * pre_ld + n);
+          pre[rr][0] = h[0]; pre[rr][1] = h[1]; pre[rr][2] = h[2]; pre[rr][3] = h[3];
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < HB; ++i)
 #pragma unroll
@@ -170,11 +190,9 @@ DEVFN void gemm_epilogue_rows(const GemmP& p, const DropKey& dk, const f32x4 (&a
       lo = lo * p.alpha + b_lo;
       hi = hi * p.alpha + b_hi;
       const bool full = n_hi;
-      if (p.epi & GSTVD_EPI_ADD) {
-        const bf16* ap = (const bf16*)p.addend + z * p.sAdd + m * p.ldadd + n;
-        if (full) { f32x4 a0, a1; ld8(ap, a0, a1); lo += a0; hi += a1; }
-        else lo += ld4(ap);
-      }
+      const f32x4 q_lo = {(float)pre[rr][0], (float)pre[rr][1], (float)pre[rr][2], (float)pre[rr][3]};
+      const f32x4 q_hi = {(float)pre[rr][4], (float)pre[rr][5], (float)pre[rr][6], (float)pre[rr][7]};
+      if (pre_add) { lo += q_lo; hi += q_hi; }
       if (p.epi & GSTVD_EPI_GELU) {
         f32x4 d0, d1;
 #pragma unroll
@@ -187,9 +205,12 @@ DEVFN void gemm_epilogue_rows(const GemmP& p, const DropKey& dk, const f32x4 (&a
         if (full) st8(xp, d0, d1); else st4(xp, d0);
       }
       if (p.epi & GSTVD_EPI_DGELU) {
-        const bf16* xp = (const bf16*)p.aux + z * p.sAux + m * p.ldaux + n;
-        if (full) { f32x4 a0, a1; ld8(xp, a0, a1); lo *= a0; hi *= a1; }
-        else lo *= ld4(xp);
+        if (pre_aux) { lo *= q_lo; hi *= q_hi; }
+        else {
+          const bf16* xp = (const bf16*)p.aux + z * p.sAux + m * p.ldaux + n;
+          if (full) { f32x4 a0, a1; ld8(xp, a0, a1); lo *= a0; hi *= a1; }
+          else lo *= ld4(xp);
+        }
       }
       if (dk.on) {
         const uint64_t e0 = (uint64_t)((z * p.M + m) * p.N + n);
