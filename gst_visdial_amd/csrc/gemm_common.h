@@ -143,13 +143,15 @@ template <int MI, int NI, int HB>
 DEVFN void gemm_epilogue_rows(const GemmP& p, const DropKey& dk, const f32x4 (&acc)[MI][NI], int64_t z, int64_t mw, int64_t nw,
                               char* lds_wave, int lane) {
   static_assert(MI % HB == 0, "row blocks per pass must divide the wave tile");
-  constexpr int S = epi_row_floats<NI>(), LPR = NI * 2, RPI = 64 / LPR, ROWS = HB * 16;
+  // lanes per row: 8 columns each, rounded up to a power of two (NI = 3: 8 lanes, the last two idle)
+  constexpr int S = epi_row_floats<NI>(), LPR = NI <= 1 ? 2 : (NI <= 2 ? 4 : 8), RPI = 64 / LPR, ROWS = HB * 16;
   const int g = lane >> 4, li = lane & 15;
   const int rl = lane / LPR, c8 = (lane % LPR) * 8;
   float* park = (float*)lds_wave;
   bf16* C = (bf16*)p.C + z * p.sC;
   const int64_t n = nw + c8;
-  const bool n_lo = n < p.N, n_hi = n + 4 < p.N;                 // N % 4 == 0: a 4-column half is all in or all out
+  const bool in_tile = c8 < NI * 16;
+  const bool n_lo = in_tile && n < p.N, n_hi = in_tile && n + 4 < p.N;   // N % 4 == 0: a 4-column half is all in or all out
   f32x4 b_lo = {0.f, 0.f, 0.f, 0.f}, b_hi = b_lo;
   if (p.epi & GSTVD_EPI_BIAS) {
     if (n_lo) b_lo = *(const f32x4*)(p.bias + n);
@@ -185,8 +187,8 @@ DEVFN void gemm_epilogue_rows(const GemmP& p, const DropKey& dk, const f32x4 (&a
     for (int rr = 0; rr < ROWS / RPI; ++rr) {
       const int row = rr * RPI + rl;
       const int64_t m = mw + pb * ROWS + row;
-      f32x4 lo = *(const f32x4*)(park + row * S + c8), hi = *(const f32x4*)(park + row * S + c8 + 4);
       if (m >= p.M || !n_lo) continue;
+      f32x4 lo = *(const f32x4*)(park + row * S + c8), hi = *(const f32x4*)(park + row * S + c8 + 4);
       lo = lo * p.alpha + b_lo;
       hi = hi * p.alpha + b_hi;
       const bool full = n_hi;

@@ -66,10 +66,12 @@ struct DmaUnits {
 // Split-K (S > 1): the tile's K range is cut into S contiguous runs of K-tiles, one workgroup each.  Every workgroup
 // parks its fp32 accumulators in `ws`, the last one to arrive (per-tile counter) adds the S partials in split order --
 // so the sum does not depend on arrival order -- and runs the epilogue; it also re-arms the counter.
-template <typename OT, int BM, int BN, int WM, int WN, bool AKM, bool BKM, int NS>
+// NIU > 0: only NIU of a wave's BN/WN/16 column tiles are used -- the output tile is WN*NIU*16 wide inside the same BN-wide
+// LDS image (96 of 128 columns with WN = 2, NIU = 3: N = 768 then makes 256 tiles, one per CU, instead of 192).
+template <typename OT, int BM, int BN, int WM, int WN, bool AKM, bool BKM, int NS, int NIU = 0>
 DEVFN void dma_tile(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char* smem, int S = 1, int split = 0,
                     float* ws = nullptr, int* cnt = nullptr) {
-  constexpr int NT = WM * WN * 64, WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
+  constexpr int NT = WM * WN * 64, WTM = BM / WM, MI = WTM / 16, NI = NIU > 0 ? NIU : BN / WN / 16, WTN = NI * 16, BNU = WN * WTN;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   constexpr int NPA = A_BYTES / (NT * 16), NPB = B_BYTES / (NT * 16), LPS = NPA + NPB;
   static_assert(NPA >= 1 && NPB >= 1, "tile too small for the thread count");
@@ -82,12 +84,12 @@ DEVFN void dma_tile(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char* s
   const int ntm = nwg / ntn;
   const int strip = wg / (4 * ntm), sw = (ntn - strip * 4) < 4 ? (ntn - strip * 4) : 4;
   const int within = wg - strip * 4 * ntm;
-  const int64_t m0 = (int64_t)(within / sw) * BM, n0 = (int64_t)(strip * 4 + within % sw) * BN;
+  const int64_t m0 = (int64_t)(within / sw) * BM, n0 = (int64_t)(strip * 4 + within % sw) * BNU;
 
   DmaUnits<BM, AKM, NPA, NT> ua;
   DmaUnits<BN, BKM, NPB, NT> ub;
   ua.init(p.A + z * p.sA * 2, p.lda, m0, p.M, tid);
-  ub.init(p.B + z * p.sB * 2, p.ldb, n0, p.N, tid);
+  ub.init(p.B + z * p.sB * 2, p.ldb, n0, (n0 + BNU < p.N) ? n0 + BNU : p.N, tid);    // columns past the tile read the zero page
 
   f32x4 acc[MI][NI];
 #pragma unroll
@@ -191,10 +193,10 @@ DEVFN int xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
-template <typename OT, int BM, int BN, int WM, int WN, bool AKM, bool BKM, int NS>
+template <typename OT, int BM, int BN, int WM, int WN, bool AKM, bool BKM, int NS, int NIU = 0>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(GemmP p, int ntn, int nwg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  dma_tile<OT, BM, BN, WM, WN, AKM, BKM, NS>(p, blockIdx.y, xcd_remap(blockIdx.x, nwg), ntn, nwg, smem);
+  dma_tile<OT, BM, BN, WM, WN, AKM, BKM, NS, NIU>(p, blockIdx.y, xcd_remap(blockIdx.x, nwg), ntn, nwg, smem);
 }
 
 template <typename OT, int BM, int BN, int WM, int WN, bool AKM, bool BKM, int NS>
@@ -204,13 +206,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_splitk_kernel(GemmP p, 
   dma_tile<OT, BM, BN, WM, WN, AKM, BKM, NS>(p, 0, id / S, ntn, ntiles, smem, S, id % S, ws, cnt);
 }
 
-template <typename OT, int BM, int BN, int WM, int WN, bool AKM, bool BKM, int NS>
+template <typename OT, int BM, int BN, int WM, int WN, bool AKM, bool BKM, int NS, int NIU = 0>
 static int dma_launch(const GemmP& p, int64_t batch, hipStream_t s) {
-  constexpr int lds = NS * (BM + BN) * 128;
-  auto k = gemm_dma_kernel<OT, BM, BN, WM, WN, AKM, BKM, NS>;
+  constexpr int lds = NS * (BM + BN) * 128, BNU = NIU > 0 ? WN * NIU * 16 : BN;
+  auto k = gemm_dma_kernel<OT, BM, BN, WM, WN, AKM, BKM, NS, NIU>;
   static int attr_rc = ensure_lds(k, lds);
   if (attr_rc) return attr_rc;
-  const int ntm = (int)((p.M + BM - 1) / BM), ntn = (int)((p.N + BN - 1) / BN);
+  const int ntm = (int)((p.M + BM - 1) / BM), ntn = (int)((p.N + BNU - 1) / BNU);
   hipLaunchKernelGGL(k, dim3((unsigned)(ntm * ntn), (unsigned)batch), dim3(WM * WN * 64), lds, s, p, ntn, ntm * ntn);
   GSTVD_LAUNCH_CHECK();
   return 0;
@@ -225,6 +227,12 @@ static int dma_layout(const GemmP& p, int64_t batch, hipStream_t s) {
   const int64_t big = ((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
   if (p.M >= 256 && p.N >= 128 && big >= 96) {
     if (variant == 2) return dma_launch<OT, 128, 128, 2, 4, AKM, BKM, 4>(p, batch, s);
+    // 96-wide tiles when they turn a partially filled round of CUs into a full one (N = 768: 192 -> 256 tiles)
+    static const int n96 = [] { const char* e = getenv("GSTVD_GEMM128_N96"); return e ? atoi(e) : 1; }();
+    const int64_t ntm = (p.M + 127) / 128, t128 = ntm * ((p.N + 127) / 128) * batch, t96 = ntm * ((p.N + 95) / 96) * batch;
+    const double nkt = (double)((p.K + 63) / 64);
+    const double c128 = (double)((t128 + 255) / 256) * (8.0 + 0.45 * nkt), c96 = (double)((t96 + 255) / 256) * (8.0 + 0.40 * nkt);
+    if (n96 == 2 || (n96 == 1 && c96 < c128)) return dma_launch<OT, 128, 128, 4, 2, AKM, BKM, 5, 3>(p, batch, s);
     return dma_launch<OT, 128, 128, 2, 4, AKM, BKM, 5>(p, batch, s);
   }
   if (variant == 3) return dma_launch<OT, 64, 64, 2, 2, AKM, BKM, 4>(p, batch, s);

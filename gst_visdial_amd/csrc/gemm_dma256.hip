@@ -76,10 +76,12 @@ struct Dma32 {
   }
 };
 
-template <typename OT, bool AKM, bool BKM, int PF>
+// NIU = 16-column accumulator tiles per wave actually used (4: the full 256-wide tile; 3: a 192-wide tile inside the same
+// 256-wide LDS image -- N = 3072 then gives 16 x 16 = 256 tiles, one per CU, instead of 192 tiles on 256 CUs).
+template <typename OT, bool AKM, bool BKM, int PF, int NIU = 4>
 DEVFN void dma_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char* smem) {
   constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NS = NS256, NT = 512;
-  constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;     // 8 x 4 accumulator tiles per wave
+  constexpr int WTM = BM / WM, WTN = NIU * 16, MI = WTM / 16, NI = NIU, BNU = WN * WTN;   // 8 x NIU accumulator tiles per wave
   constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;
   constexpr int NPA = A_BYTES / (NT * 16), NPB = B_BYTES / (NT * 16), LPS = NPA + NPB;
 
@@ -90,12 +92,12 @@ DEVFN void dma_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char
   const int ntm = nwg / ntn;
   const int strip = wg / (2 * ntm), sw = (ntn - strip * 2) < 2 ? (ntn - strip * 2) : 2;
   const int within = wg - strip * 2 * ntm;
-  const int64_t m0 = (int64_t)(within / sw) * BM, n0 = (int64_t)(strip * 2 + within % sw) * BN;
+  const int64_t m0 = (int64_t)(within / sw) * BM, n0 = (int64_t)(strip * 2 + within % sw) * BNU;
 
   Dma32<BM, AKM, NPA, NT> ua;
   Dma32<BN, BKM, NPB, NT> ub;
   ua.init(p.A + z * p.sA * 2, p.lda, m0, p.M, tid);
-  ub.init(p.B + z * p.sB * 2, p.ldb, n0, p.N, tid);
+  ub.init(p.B + z * p.sB * 2, p.ldb, n0, (n0 + BNU < p.N) ? n0 + BNU : p.N, tid);     // columns past the tile read the zero page
 
   f32x4 acc[MI][NI];
 #pragma unroll
@@ -280,11 +282,11 @@ DEVFN int xcd_remap256(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
-template <typename OT, bool AKM, bool BKM, int PF>
+template <typename OT, bool AKM, bool BKM, int PF, int NIU = 4>
 __global__ __launch_bounds__(512) void gemm_dma256_kernel(GemmP p, int ntn, int nwg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (PF == -5) pp_tile256<OT, AKM, BKM>(p, blockIdx.y, xcd_remap256(blockIdx.x, nwg), ntn, nwg, smem);
-  else dma_tile256<OT, AKM, BKM, PF>(p, blockIdx.y, xcd_remap256(blockIdx.x, nwg), ntn, nwg, smem);
+  else dma_tile256<OT, AKM, BKM, PF, NIU>(p, blockIdx.y, xcd_remap256(blockIdx.x, nwg), ntn, nwg, smem);
 }
 
 template <typename OT, bool AKM, bool BKM, int PF>
@@ -311,27 +313,42 @@ __global__ __launch_bounds__(512) void gemm_dma256_grouped_kernel(const gstvd_ge
 constexpr int LDS256 = NS256 * (256 + 256) * 64;           // the ring is the whole LDS of a CU
 
 template <typename OT, bool AKM, bool BKM>
-static int launch256(const GemmP& p, int64_t batch, hipStream_t s) {
+static int launch256(const GemmP& p, int64_t batch, int niu, hipStream_t s) {
   auto k0 = gemm_dma256_kernel<OT, AKM, BKM, 0>;
+  auto k3 = gemm_dma256_kernel<OT, AKM, BKM, 0, 3>;
   auto ka = gemm_dma256_kernel<OT, AKM, BKM, -1>;
   auto kb = gemm_dma256_kernel<OT, AKM, BKM, -2>;
   auto ke = gemm_dma256_kernel<OT, AKM, BKM, -5>;
   auto kf = gemm_dma256_kernel<OT, AKM, BKM, -6>;
-  static int attr_rc = ensure_lds(k0, LDS256) | ensure_lds(ka, LDS256) | ensure_lds(kb, LDS256) | ensure_lds(ke, LDS256) | ensure_lds(kf, LDS256);
+  static int attr_rc = ensure_lds(k0, LDS256) | ensure_lds(k3, LDS256) | ensure_lds(ka, LDS256) | ensure_lds(kb, LDS256) |
+                       ensure_lds(ke, LDS256) | ensure_lds(kf, LDS256);
   if (attr_rc) return attr_rc;
   static const int abl = [] { const char* e = getenv("GSTVD_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
-  const int ntm = (int)((p.M + 255) / 256), ntn = (int)((p.N + 255) / 256);
-  hipLaunchKernelGGL(abl == 1 ? ka : abl == 2 ? kb : abl == 5 ? ke : abl == 6 ? kf : k0, dim3((unsigned)(ntm * ntn), (unsigned)batch), dim3(512), LDS256, s, p, ntn, ntm * ntn);
+  const int bnu = (niu == 3 && abl == 0) ? 192 : 256;
+  const int ntm = (int)((p.M + 255) / 256), ntn = (int)((p.N + bnu - 1) / bnu);
+  hipLaunchKernelGGL(abl == 1 ? ka : abl == 2 ? kb : abl == 5 ? ke : abl == 6 ? kf : (bnu == 192 ? k3 : k0),
+                     dim3((unsigned)(ntm * ntn), (unsigned)batch), dim3(512), LDS256, s, p, ntn, ntm * ntn);
   GSTVD_LAUNCH_CHECK();
   return 0;
 }
 
 template <typename OT>
-static int launch256_layout(const GemmP& p, int64_t batch, int akm, int bkm, hipStream_t s) {
-  if (!akm && !bkm) return launch256<OT, false, false>(p, batch, s);
-  if (!akm && bkm) return launch256<OT, false, true>(p, batch, s);
-  if (akm && bkm) return launch256<OT, true, true>(p, batch, s);
+static int launch256_layout(const GemmP& p, int64_t batch, int akm, int bkm, int niu, hipStream_t s) {
+  if (!akm && !bkm) return launch256<OT, false, false>(p, batch, niu, s);
+  if (!akm && bkm) return launch256<OT, false, true>(p, batch, niu, s);
+  if (akm && bkm) return launch256<OT, true, true>(p, batch, niu, s);
   return GSTVD_E_UNSUPPORTED;
+}
+
+// Tile width: 256 columns, or 192 when that needs fewer rounds of 256 CUs for the work it does.  Cost model from the
+// measured kernel: ~14 us fixed + 0.95 us per 32-deep K step for the full tile, ~0.9x that per step for the 192 one.
+static int pick_niu(const GemmP& p, int64_t batch) {
+  static const int force = [] { const char* e = getenv("GSTVD_GEMM256_NIU"); return e ? atoi(e) : 0; }();
+  if (force == 3 || force == 4) return force;
+  const double nkt = (double)((p.K + 31) / 32), ntm = (double)((p.M + 255) / 256);
+  const double t4 = ntm * (double)((p.N + 255) / 256) * batch, t3 = ntm * (double)((p.N + 191) / 192) * batch;
+  const double r4 = (double)(int64_t)((t4 + 255) / 256), r3 = (double)(int64_t)((t3 + 255) / 256);
+  return r3 * (14.0 + 0.84 * nkt) < r4 * (14.0 + 0.95 * nkt) ? 3 : 4;     // measured 0.73 vs 0.82 us per step at K = 768
 }
 
 // Single-problem policy: the big tile only pays when its (4x smaller) grid still covers most of the chip.
@@ -341,7 +358,8 @@ int gemm_dma256_dispatch(const GemmP& p, int64_t batch, int akm, int bkm, int ou
   if (variant == 1 || variant == 2 || variant == 4) return GSTVD_E_UNSUPPORTED;
   const int64_t tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256) * batch;
   if (p.M < 256 || p.N < 256 || tiles < min_tiles) return GSTVD_E_UNSUPPORTED;
-  return out_f32 ? launch256_layout<float>(p, batch, akm, bkm, s) : launch256_layout<bf16>(p, batch, akm, bkm, s);
+  const int niu = pick_niu(p, batch);
+  return out_f32 ? launch256_layout<float>(p, batch, akm, bkm, niu, s) : launch256_layout<bf16>(p, batch, akm, bkm, niu, s);
 }
 
 template <typename OT, bool AKM, bool BKM>
