@@ -210,14 +210,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(gstvd_attn_t a) {
 
   // chunk c+1's K / V / mask loads are issued right after chunk c has been parked in LDS and fly during its compute
   Stage64<T, D> pk, pv;
-  float pm = 2.f;
+  float pm = -INFINITY;
   auto prefetch = [&](int c0) {
     pk.load(Kb, a.ldk, c0, a.Lk, tid);
     pv.load(Vb, a.ldv, c0, a.Lk, tid);
-    if (tid < 64) {
+    if (tid < 64) {      // additive mask term of the key: 0 (valid), mask_neg (masked out), -inf (past the end)
       const int key = c0 + tid;
-      pm = 2.f;
-      if (key < a.Lk) pm = (a.key_mask == nullptr || a.key_mask[(int64_t)bk * a.Lk + key] != 0.f) ? 0.f : 1.f;
+      pm = -INFINITY;
+      if (key < a.Lk) pm = (a.key_mask == nullptr || a.key_mask[(int64_t)bk * a.Lk + key] != 0.f) ? 0.f : a.mask_neg;
     }
   };
   prefetch(0);
@@ -231,19 +231,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(gstvd_attn_t a) {
     const int ntile = (a.Lk - c0 + 15) / 16 < 4 ? (a.Lk - c0 + 15) / 16 : 4;
     for (int t = 0; t < ntile; ++t) {
       f32x4 s = first_product<T, D>(sK, t * 16, qf, lane);
+      f32x4 madd = *(const f32x4*)(smask + t * 16 + 4 * g);
+      if (a.causal) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (c0 + t * 16 + 4 * g + r > q && madd[r] == 0.f) madd[r] = a.mask_neg;     // causal x padding: the term is added once
+      }
       float val[4], mx = -INFINITY;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int kl = t * 16 + 4 * g + r, key = c0 + kl;
-        const float mv = smask[kl];
-        const bool masked = (mv == 1.f) || (a.causal && key > q);
-        val[r] = (mv == 2.f) ? -INFINITY : s[r] * a.scale + (masked ? a.mask_neg : 0.f);
+        val[r] = s[r] * a.scale + madd[r];
         mx = fmaxf(mx, val[r]);
       }
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run, mx);
-      const float alpha = __expf(m_run - m_new);
       const f32x4 fac = drop_factor4(dk, ebase + (uint64_t)(c0 + t * 16 + 4 * g));
       float pd[4], ps = 0.f;
 #pragma unroll
@@ -252,11 +254,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(gstvd_attn_t a) {
         ps += p;
         pd[r] = p * fac[r];
       }
-      l_part = l_part * alpha + ps;
+      if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {       // the running max moved for some query of this wave
+        const float alpha = __expf(m_run - m_new);
+        l_part *= alpha;
 #pragma unroll
-      for (int i = 0; i < D / 16; ++i) accO[i] *= alpha;
+        for (int i = 0; i < D / 16; ++i) accO[i] *= alpha;
+        m_run = m_new;
+      }
+      l_part += ps;
       second_product<T, D>(accO, sV, t * 16, pd, lane);
-      m_run = m_new;
     }
   }
   float l_tot = l_part + __shfl_xor(l_part, 16, 64);
@@ -308,14 +314,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(gstvd_attn_t a) {
   for (int i = 0; i < D / 16; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   Stage64<T, D> pk, pv;
-  float pm = 2.f;
+  float pm = -INFINITY;
   auto prefetch = [&](int c0) {
     pk.load(Kb, a.ldk, c0, a.Lk, tid);
     pv.load(Vb, a.ldv, c0, a.Lk, tid);
-    if (tid < 64) {
+    if (tid < 64) {      // additive mask term of the key: 0 (valid), mask_neg (masked out), -inf (past the end)
       const int key = c0 + tid;
-      pm = 2.f;
-      if (key < a.Lk) pm = (a.key_mask == nullptr || a.key_mask[(int64_t)b * a.Lk + key] != 0.f) ? 0.f : 1.f;
+      pm = -INFINITY;
+      if (key < a.Lk) pm = (a.key_mask == nullptr || a.key_mask[(int64_t)b * a.Lk + key] != 0.f) ? 0.f : a.mask_neg;
     }
   };
   prefetch(0);
@@ -331,13 +337,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(gstvd_attn_t a) {
       const f32x4 s = first_product<T, D>(sKr, t * 16, qf, lane);
       const f32x4 dp = first_product<T, D>(sVr, t * 16, dof, lane);
       const f32x4 fac = drop_factor4(dk, ebase + (uint64_t)(c0 + t * 16 + 4 * g));
+      f32x4 madd = *(const f32x4*)(smask + t * 16 + 4 * g);
+      if (a.causal) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (c0 + t * 16 + 4 * g + r > q && madd[r] == 0.f) madd[r] = a.mask_neg;
+      }
       float ds[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int kl = t * 16 + 4 * g + r, key = c0 + kl;
-        const float mv = smask[kl];
-        const bool masked = (mv == 1.f) || (a.causal && key > q);
-        const float val = (mv == 2.f) ? -INFINITY : s[r] * a.scale + (masked ? a.mask_neg : 0.f);
+        const float val = s[r] * a.scale + madd[r];
         const float p = qv ? __expf(val - lse) : 0.f;
         ds[r] = p * (dp[r] * fac[r] - delta) * a.scale;
       }
