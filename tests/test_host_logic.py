@@ -208,3 +208,33 @@ def test_product_package_never_imports_oracle():
         if fn.endswith(".py"):
             with open(os.path.join(pkg, fn)) as f:
                 assert not pat.search(f.read()), fn
+
+
+def test_bench_synthetic_rows_follow_the_survey_generator():
+    """the synthetic batch bench.py times has the structure train_gen.forward hands to the model."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    B, T, R, U, F, V = 6, 64, 37, 25, 32, 30522
+    b = bench.synthetic_rows(B, T, R, U, F, V, 1234, "cpu")
+    b2 = bench.synthetic_rows(B, T, R, U, F, V, 1234, "cpu")
+    assert all(torch.equal(b[k], b2[k]) for k in b)                              # seeded
+    ids, att, seg = b["enc_input_ids"], b["enc_attention_mask"], b["enc_segments"]
+    assert ids.shape == (B, T) and (ids[:, 0] == 101).all()
+    assert torch.equal(att, (ids != 0).float())
+    lens = att.sum(1)
+    assert (lens >= 0.6 * T - 1).all() and (lens <= T).all()
+    assert ((ids == 0) | (ids == 101) | (ids == 102) | ((ids >= 1000) & (ids < 30000))).all()
+    assert set(seg.unique().tolist()) <= {0, 1} and (seg[ids == 0] == 0).all()
+    assert b["enc_image_features"].shape == (B, R, F) and (b["enc_image_features"] >= 0).all()
+    assert torch.allclose(b["enc_image_features"][:, 0], b["enc_image_features"][:, 1:].mean(1), atol=1e-6)
+    assert torch.equal(b["enc_image_spatials"][:, 0], torch.tensor([0., 0., 1., 1., 1.]).expand(B, 5))
+    dec, lab, dmask = b["dec_input_ids"], b["dec_labels"], b["dec_attention_mask"]
+    assert (dec[:, 0] == 101).all() and dec.shape == lab.shape == (B, U)
+    for r in range(B):                                                           # labels = decoder ids shifted left + [SEP]
+        n = int((lab[r] != 0).sum())
+        assert lab[r, n - 1] == 102 and (lab[r, n:] == 0).all()
+        assert torch.equal(dec[r, 1:n], lab[r, :n - 1]) and (dec[r, n:] == 0).all()
+        assert dmask[r].sum() >= n
