@@ -33,13 +33,25 @@ def score_batch(model, batch, device, rounds_per_call=20):
 
 
 @torch.no_grad()
-def evaluate(model, dataloader, params, mode="vd_eval_val"):
-    """Returns (ranks_json, metrics) like evaluate_gen.evaluate + its logged metric dict."""
+def evaluate(model, dataloader, params, mode="vd_eval_val", scorer=None, group=None):
+    """Returns (ranks_json, metrics) like evaluate_gen.evaluate + its logged metric dict.
+
+    Multi-GPU: with an initialised process group the dialogs are sharded by batch index (batch i goes to
+    rank i % world), there is no exchange on the data path, and the metric state -- the ground-truth ranks, the NDCG
+    sums, the ranks json -- is all-gathered once at the end, so every rank returns the metrics of the whole set.
+    `scorer(model, batch, device) -> [B, rounds, options]` defaults to `score_batch`."""
+    import torch.distributed as dist
+    scorer = scorer or score_batch
     sparse, ndcg, ranks_json = SparseGTMetrics(), NDCG(), []
-    model.eval()
+    if hasattr(model, "eval"):
+        model.eval()
     device = params["device"]
-    for batch in dataloader:
-        scores = score_batch(model, batch, device)
+    sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    rank, world = (dist.get_rank(group), dist.get_world_size(group)) if sharded else (0, 1)
+    for i, batch in enumerate(dataloader):
+        if i % world != rank:
+            continue
+        scores = scorer(model, batch, device)
         if mode == "vd_eval_val":
             sparse.observe(scores, batch["gt_option_inds"])
             if params.get("vd_version", "1.0") == "1.0" and "gt_relevance" in batch:
@@ -47,9 +59,15 @@ def evaluate(model, dataloader, params, mode="vd_eval_val"):
                 ndcg.observe(scores[torch.arange(scores.size(0)), rid - 1, :], batch["gt_relevance"])
         else:
             ranks = scores_to_ranks(scores).squeeze(1)
-            for i in range(scores.shape[0]):
-                ranks_json.append({"image_id": batch["image_id"][i].item(), "round_id": int(batch["round_id"][i].item()),
-                                   "ranks": [r.item() for r in ranks[i][:]]})
+            for j in range(scores.shape[0]):
+                ranks_json.append({"image_id": batch["image_id"][j].item(), "round_id": int(batch["round_id"][j].item()),
+                                   "ranks": [r.item() for r in ranks[j][:]]})
+    if sharded:
+        parts = [None] * world
+        dist.all_gather_object(parts, (sparse._ranks, ndcg._num, ndcg._den, ranks_json), group=group)
+        sparse._ranks = [r for p in parts for r in p[0]]
+        ndcg._num, ndcg._den = sum(p[1] for p in parts), sum(p[2] for p in parts)
+        ranks_json = [e for p in parts for e in p[3]]
     metrics = {}
     if mode == "vd_eval_val":
         metrics.update(sparse.retrieve(reset=True))

@@ -118,3 +118,46 @@ def test_backward_pipeline_slices_world2():
         for (lo, hi), (lo2, hi2) in zip(slices, slices[1:]):
             assert hi2 == lo
         assert all(hi - lo >= chunk for lo, hi in slices[:-1])
+
+
+def _eval_batches():
+    g = torch.Generator().manual_seed(7)
+    out = []
+    for i in range(5):
+        B, R_, O = 2, 3, 6
+        out.append(dict(scores=torch.randn(B, R_, O, generator=g), gt_option_inds=torch.randint(0, O, (B, R_), generator=g),
+                        round_id=torch.randint(1, R_ + 1, (B, 1), generator=g),
+                        gt_relevance=(torch.rand(B, O, generator=g) > 0.5).float() * torch.rand(B, O, generator=g)))
+    for b in out:
+        b["gt_relevance"][:, 0] = 1.0          # at least one relevant option per dialog
+    return out
+
+
+def _eval_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gst_visdial_amd.evaluate import evaluate
+    _, m = evaluate(None, _eval_batches(), dict(device="cpu", vd_version="1.0"), scorer=lambda mod, b, d: b["scores"])
+    q.put((rank, m))
+    dist.destroy_process_group()
+
+
+def test_sharded_evaluation_world2_matches_single_process():
+    """evaluate_gen over 2 ranks: dialogs sharded by batch index, no data-path exchange, metric state all-gathered once."""
+    from gst_visdial_amd.evaluate import evaluate
+    _, ref = evaluate(None, _eval_batches(), dict(device="cpu", vd_version="1.0"), scorer=lambda mod, b, d: b["scores"])
+    assert set(ref) == {"r@1", "r@5", "r@10", "mean", "mrr", "ndcg"}
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eval_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, m in res:
+        for k in ref:
+            assert abs(m[k] - ref[k]) < 1e-6, (rank, k, m[k], ref[k])
