@@ -1027,4 +1027,34 @@ def standalone_encoder_forward(module, input_ids, image_feat, image_loc, token_t
 
 
 def standalone_decoder_forward(module, dec_ids, attention_mask, enc_hidden, enc_mask, labels, loss_reduction):
-    raise GstvdError("VisualDialogDecoder.forward outside an EncoderDecoderModel is not supported by the MI355X engine")
+    """VisualDialogDecoder.forward on caller-supplied encoder states (models/visual_dialog_decoder.py:33-86), inference
+    only: the training graph lives in EncoderDecoderModel's single autograd function.  Same conventions as the reference:
+    labels=None -> labels are the ids shifted left and the caller's `decoder_input_ids` has [SEP] replaced by [PAD] in place."""
+    eng = _owner_engine(module, "VisualDialogDecoder")
+    if torch.is_grad_enabled() and (enc_hidden.requires_grad or module.training):
+        raise GstvdError("VisualDialogDecoder.forward alone is inference only on the MI355X engine (eval() + torch.no_grad()); "
+                         "train through EncoderDecoderModel(...)")
+    with torch.no_grad():
+        eng._begin(dec_ids.device, False)
+        eng.train = False
+        dc = eng.dec_cfg
+        if labels is None:
+            labels = dec_ids.new_zeros(dec_ids.shape)
+            labels[:, :-1] = dec_ids[:, 1:].clone()
+            dec_ids.masked_fill_(dec_ids == dc.eos_token_id, dc.pad_token_id)
+        Bn, S, H = enc_hidden.shape
+        U, V = dec_ids.shape[1], dc.vocab_size
+        if H != dc.hidden_size:
+            raise GstvdError("encoder_hidden_states width %d != decoder hidden size %d" % (H, dc.hidden_size))
+        enc = eng.act(Bn * S, H)
+        enc.t.copy_(enc_hidden.reshape(Bn * S, H))
+        em = enc_mask if enc_mask is not None else torch.ones(Bn, S, device=dec_ids.device)
+        dm = attention_mask if attention_mask is not None else torch.ones(Bn, U, device=dec_ids.device)
+        I = dict(B=Bn, T=S, R=0, U=U, emask=em.float().contiguous(), dmask=dm.float().contiguous(),
+                 dec_ids=dec_ids.contiguous().view(-1))
+        y, logits = eng.decoder(enc, I)
+        Md = Bn * U
+        row_loss, lse, stats = eng.vec(Md), eng.vec(Md), eng.vec(4)
+        ops.ce_fwd(logits.t, labels.contiguous().view(-1), Md, V, row_loss, lse, stats, ignore_index=dc.pad_token_id)
+        loss = stats[2].clone() if loss_reduction else row_loss.clone()
+        return loss, logits.t.view(Bn, U, eng.flat.Vp)[:, :, :V].float()

@@ -335,6 +335,7 @@ class EncoderDecoderModel(nn.Module):
             from .engine import Engine
             self._engine = Engine(self)
             object.__setattr__(self.encoder, "_standalone_engine", self._engine)
+            object.__setattr__(self.decoder, "_standalone_engine", self._engine)
         return self._engine
 
     def score_candidates(self, enc_image_features, enc_image_spatials, enc_image_mask, enc_input_ids, enc_segments,

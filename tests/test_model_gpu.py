@@ -398,3 +398,34 @@ def test_step_forward_row_sampling_matches_oracle_on_selected_rows():
     ref = O.model_forward(load_npz("tiny_state.npz"), cfg["enc"], cfg["dec"], ob)
     assert abs(loss.item() - ref["loss"].item()) < 1e-5
     assert maxerr(scores, ref["logits"]) < 1e-4
+
+
+def test_standalone_encoder_and_decoder_compose_to_the_full_model():
+    """The reference's module API also allows calling the two halves by hand (visual_dialog_model.py:40-72 does exactly
+    that): VisualDialogEncoder(...) -> 7-tuple, VLFusion in plain torch, VisualDialogDecoder(...) -> .loss/.logits.
+    In eval mode this must reproduce EncoderDecoderModel(...)'s golden loss / logits."""
+    s = sc()
+    model, params, cfg = s.build_tiny_model("fp32", DEV, mode="vd_eval_val")
+    model.eval()
+    g = load_npz("tiny_train.npz")
+    kw = s.golden_batch(g, DEV)
+    with torch.no_grad():
+        model.engine                                        # builds the engine that both halves share
+        out = model.encoder(kw["enc_input_ids"], kw["enc_image_features"], kw["enc_image_spatials"],
+                            token_type_ids=kw["enc_segments"], attention_mask=kw["enc_attention_mask"],
+                            image_attention_mask=kw["enc_image_mask"])
+        assert len(out) == 7 and all(o is None for o in out[:5])
+        enc_t, enc_v = out[5], out[6]
+        assert maxerr(enc_t, g["enc_hidden_t"]) < 1e-4 and maxerr(enc_v, g["enc_hidden_v"]) < 1e-4
+        vl = model.vlfusion                                 # visual_dialog_model.py:131-135 (eval: dropout off), vision first
+        fused = torch.cat((torch.nn.functional.linear(enc_v, vl.fc_v.weight, vl.fc_v.bias),
+                           torch.nn.functional.linear(enc_t, vl.fc_l.weight, vl.fc_l.bias)), dim=1)
+        mask = torch.cat((kw["enc_image_mask"], kw["enc_attention_mask"]), dim=1)
+        res = model.decoder(decoder_input_ids=kw["dec_input_ids"], attention_mask=kw["dec_attention_mask"],
+                            encoder_hidden_states=fused, encoder_attention_mask=mask, labels=kw["dec_labels"])
+    assert maxerr(res.logits, g["logits"]) < 1e-4
+    assert abs(res.loss.item() - g["loss"].item()) < 1e-5
+    with pytest.raises(Exception):                          # training through the bare decoder is refused loudly
+        model.train()
+        model.decoder(decoder_input_ids=kw["dec_input_ids"], attention_mask=kw["dec_attention_mask"],
+                      encoder_hidden_states=fused, encoder_attention_mask=mask, labels=kw["dec_labels"])
