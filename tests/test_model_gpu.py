@@ -429,3 +429,79 @@ def test_standalone_encoder_and_decoder_compose_to_the_full_model():
         model.train()
         model.decoder(decoder_input_ids=kw["dec_input_ids"], attention_mask=kw["dec_attention_mask"],
                       encoder_hidden_states=fused, encoder_attention_mask=mask, labels=kw["dec_labels"])
+
+
+@pytest.mark.parametrize("B,T,R,U", [(1, 17, 5, 3), (5, 33, 7, 9), (2, 24, 1, 1), (7, 8, 3, 12)])
+def test_odd_shapes_match_oracle(B, T, R, U):
+    """Shapes the golden fixtures do not hold: a single row, lengths that are not multiples of the vector width / MFMA
+    tile, one image region, a one-token answer, ragged padding incl. a fully padded tail -- fp32 mode against the oracle
+    on the same inputs (logits 1e-4, loss 1e-5, a few gradients)."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import vd_oracle as O
+    s = sc()
+    model, params, cfg = s.build_tiny_model("fp32", DEV)
+    model.eval()
+    sd = load_npz("tiny_state.npz")
+    V, F = cfg["enc"]["vocab_size"], cfg["enc"]["v_feature_size"]
+    g = torch.Generator().manual_seed(B * 1000 + T * 10 + U)
+    ids = torch.randint(5, V, (B, T), generator=g)
+    ids[:, 0] = 1
+    lens = torch.randint(max(2, T // 3), T + 1, (B,), generator=g)
+    lens[0] = T
+    keep = torch.arange(T)[None] < lens[:, None]
+    ids = ids * keep
+    seg = (torch.randint(0, 4, (B, T), generator=g)) * keep            # includes the extension segment ids (>= 2)
+    img_mask = torch.ones(B, R)
+    if R > 2:
+        img_mask[-1, -1] = 0
+    alen = torch.randint(1, U + 1, (B,), generator=g)
+    dec = torch.randint(5, V, (B, U), generator=g) * (torch.arange(U)[None] < alen[:, None])
+    dec[:, 0] = 1
+    labels = torch.randint(5, V, (B, U), generator=g) * (torch.arange(U)[None] < alen[:, None])
+    batch = dict(enc_image_features=torch.randn(B, R, F, generator=g).abs(), enc_image_spatials=torch.rand(B, R, 5, generator=g),
+                 enc_image_mask=img_mask, enc_input_ids=ids, enc_segments=seg, enc_attention_mask=(ids != 0).float(),
+                 dec_input_ids=dec, dec_attention_mask=(dec != 0).float(), dec_labels=labels)
+    keys = ["vlfusion.fc_l.weight", "encoder.bert_pretrained.bert.encoder.layer.0.attention.self.key.weight",
+            "decoder.decoder.bert.encoder.layer.1.crossattention.self.value.weight", "decoder.decoder.lm_head.bias"]
+    out, gref, dfe = O.grads(sd, cfg["enc"], cfg["dec"], batch, keys, wrt_feats=True)
+    kw = {k: v.clone().to(DEV) for k, v in batch.items()}
+    kw["enc_image_features"].requires_grad_(True)
+    loss, logits = model(**kw)
+    assert logits.shape == (B, U, V)
+    assert maxerr(logits, out["logits"].detach()) < 1e-4
+    assert abs(loss.item() - out["loss"].item()) < 1e-5 * max(1.0, abs(out["loss"].item()))
+    loss.backward()
+    named = dict(model.named_parameters())
+    for k in keys:
+        ref = gref[k]
+        if k in named and ref.abs().max() > 0:
+            assert maxerr(named[k].grad, ref) <= 2e-4 * ref.abs().max().item() + 1e-7, k
+    assert maxerr(kw["enc_image_features"].grad, dfe) <= 2e-4 * dfe.abs().max().item() + 1e-7
+
+
+def test_invalid_inputs_fail_loudly():
+    """The reference asserts on device (vilbert_dialog.py:339) / fails in the embedding lookup; here: typed errors up front."""
+    from gst_visdial_amd._lib import GstvdError
+    s = sc()
+    model, params, cfg = s.build_tiny_model("fp32", DEV)
+    model.eval()
+    g = load_npz("tiny_train.npz")
+    kw = s.golden_batch(g, DEV)
+    bad = dict(kw)
+    bad["enc_input_ids"] = kw["enc_input_ids"].clone()
+    bad["enc_input_ids"][0, 1] = cfg["enc"]["vocab_size"] + 3
+    with pytest.raises(GstvdError):
+        model(**bad)
+    model2, _, _ = s.build_tiny_model("fp32", DEV)
+    model2.eval()
+    T = cfg["enc"]["max_position_embeddings"] + 1
+    B = kw["enc_input_ids"].shape[0]
+    long = dict(kw)
+    long["enc_input_ids"] = torch.ones(B, T, dtype=torch.long, device=DEV)
+    long["enc_segments"] = torch.zeros(B, T, dtype=torch.long, device=DEV)
+    long["enc_attention_mask"] = torch.ones(B, T, device=DEV)
+    with pytest.raises(GstvdError):
+        model2(**long)
+    with pytest.raises(Exception):                          # host tensors: no CPU fallback
+        model2(**{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in kw.items()})
