@@ -481,3 +481,15 @@ def test_attention_kv_cache_strides_and_shared_kv(dtype):
     ref, _ = attn_ref(Q.float().view(Bq, Lq, nh, d), rep(K.float().view(2, Lk2, nh, d)), rep(V.float().view(2, Lk2, nh, d)),
                       rep(km), False, -1e9, 1 / math.sqrt(d), None)
     check("attn_shared_kv", O.view(Bq, Lq, nh, d), ref, dtype, 2.0)
+
+
+def test_gemm_randomised_regression():
+    """tools/gemm_fuzz.py: random shapes / layouts / leading-dimension padding / epilogue combinations (bias, addend, GELU
+    with its aux output, x gelu', dropout, alpha, fp32 output) against torch fp32 -- every tile kernel, the narrow-tile
+    variants, split-K and both epilogue paths get hit."""
+    import importlib.util, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gemm_fuzz", os.path.join(root, "tools", "gemm_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(120, seed=11, verbose=False) == 0
