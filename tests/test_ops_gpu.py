@@ -309,6 +309,10 @@ ATTN_CASES = [
     (3, 12, 25, 25, 64, True, -10000.0, 0.1, True),     # decoder causal self-attention
     (2, 12, 25, 293, 64, False, -1e9, 0.1, False),      # decoder cross-attention
     (2, 2, 9, 31, 32, True, -10000.0, 0.0, False),      # ragged tiny
+    (2, 4, 65, 65, 64, False, -10000.0, 0.1, True),     # one row / one key spills into a second 64-chunk
+    (1, 2, 130, 128, 64, False, -10000.0, 0.0, False),  # key count an exact multiple of the chunk
+    (2, 2, 100, 100, 64, True, -10000.0, 0.1, True),    # causal across chunk boundaries
+    (1, 4, 1, 200, 128, False, -1e9, 0.0, False),       # a single query (decode step shape)
 ]
 
 
