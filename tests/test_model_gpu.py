@@ -505,3 +505,56 @@ def test_invalid_inputs_fail_loudly():
         model2(**long)
     with pytest.raises(Exception):                          # host tensors: no CPU fallback
         model2(**{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in kw.items()})
+
+
+def test_training_trajectory_matches_oracle_autograd_plus_reference_adamw():
+    """Four optimizer steps on the tiny model (fp32 mode, dropout off): the engine's backward + fused AdamW against an
+    independent trajectory -- the oracle's autograd gradients on the CPU and a from-scratch restatement of
+    pytorch_transformers-1.2.0 AdamW (train_gen.py:204-247: decay 0 for bias / LayerNorm tensors, eps outside the sqrt,
+    bias correction folded into the step size, decoupled decay after the update) with the warm-up schedule."""
+    import math, os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import vd_oracle as O
+    from gst_visdial_amd.optim import FusedAdamW, warmup_linear_nonzero
+    s = sc()
+    model, params, cfg = s.build_tiny_model("fp32", DEV)
+    model.eval()                                            # dropout off; gradients still flow (grad mode is on)
+    g = load_npz("tiny_train.npz")
+    kw = s.golden_batch(g, DEV)
+    base_lr, wd, b1, b2, eps, warm, total = 3e-3, 0.01, 0.9, 0.999, 1e-6, 2, 50
+    opt = FusedAdamW(model, lr=base_lr, weight_decay=wd, warmup_steps=warm, t_total=total, min_lr=1e-5)
+    sd = {k: v.clone() for k, v in load_npz("tiny_state.npz").items()}
+    keys = [k for k in O.live_param_keys(sd) if k in sd]
+    cpu_b = {k[4:]: v.clone() for k, v in g.items() if k.startswith("in::")}
+    m = {k: torch.zeros_like(sd[k]) for k in keys}
+    v = {k: torch.zeros_like(sd[k]) for k in keys}
+    losses_ref, losses = [], []
+    for step in range(1, 5):
+        # --- reference trajectory
+        out, grads, _ = O.grads(sd, cfg["enc"], cfg["dec"], cpu_b, keys, wrt_feats=False)
+        losses_ref.append(out["loss"].item())
+        lr = warmup_linear_nonzero(step - 1, warm, total, base_lr, 1e-5)       # scheduler.step() follows optimizer.step()
+        for k in keys:
+            gk = grads[k]
+            if gk is None:
+                continue
+            m[k].mul_(b1).add_(gk, alpha=1 - b1)
+            v[k].mul_(b2).addcmul_(gk, gk, value=1 - b2)
+            step_size = lr * math.sqrt(1 - b2 ** step) / (1 - b1 ** step)
+            sd[k] = sd[k] - step_size * (m[k] / (v[k].sqrt() + eps))
+            decay = 0.0 if any(nd in k for nd in ("bias", "LayerNorm.bias", "LayerNorm.weight")) else wd
+            if decay > 0:
+                sd[k] = sd[k] - lr * decay * sd[k]
+        # --- the engine
+        loss, _ = model(**kw)
+        loss.backward()
+        opt.step()
+        opt.scheduler_step()
+        opt.zero_grad()
+        losses.append(loss.item())
+    for a, b in zip(losses, losses_ref):
+        assert abs(a - b) < 2e-4 * max(1.0, abs(b)), (losses, losses_ref)
+    assert losses[-1] < losses[0]
+    got = {k: t.detach().float().cpu() for k, t in model.state_dict().items()}
+    worst = max(((got[k] - sd[k]).abs().max().item() / max(sd[k].abs().max().item(), 1e-6), k) for k in keys if k in got)
+    assert worst[0] < 2e-3, worst
