@@ -114,6 +114,11 @@ def load():
         raise GstvdError(
             "gst_visdial_amd: HIP library %s not found; build it first (make -C gst_visdial_amd/csrc). "
             "There is no CPU fallback for the product path." % LIB_PATH)
+    # torch first: its wheel bundles its own HIP runtime (libamdhip64).  If this library were dlopen'ed before torch, the
+    # loader would pull in /opt/rocm's copy for it and torch would then bring a second runtime into the process -- kernels
+    # registered with one, streams and allocations owned by the other (observed: hipErrorNoDevice on the first launch).
+    # With torch loaded first the dependency resolves to the runtime already in the process.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
