@@ -558,3 +558,29 @@ def test_training_trajectory_matches_oracle_autograd_plus_reference_adamw():
     got = {k: t.detach().float().cpu() for k, t in model.state_dict().items()}
     worst = max(((got[k] - sd[k]).abs().max().item() / max(sd[k].abs().max().item(), 1e-6), k) for k in keys if k in got)
     assert worst[0] < 2e-3, worst
+
+
+def test_bf16_training_tracks_fp32_training():
+    """Ten optimizer steps, dropout off: the bf16 engine's loss curve stays within a few percent of the fp32 engine's
+    (bf16 activations / shadow weights, fp32 master weights, optimizer state, LN / softmax / CE statistics)."""
+    from gst_visdial_amd.optim import FusedAdamW
+    s = sc()
+    g = load_npz("tiny_train.npz")
+    curves = {}
+    for prec in ("fp32", "bf16"):
+        model, params, cfg = s.build_tiny_model(prec, DEV)
+        model.eval()
+        kw = s.golden_batch(g, DEV)
+        opt = FusedAdamW(model, lr=2e-3, warmup_steps=0, t_total=0)
+        losses = []
+        for _ in range(10):
+            loss, _ = model(**kw)
+            loss.backward()
+            opt.step()
+            opt.zero_grad()
+            losses.append(loss.item())
+        curves[prec] = losses
+    a, b = curves["fp32"], curves["bf16"]
+    assert a[-1] < 0.8 * a[0] and b[-1] < 0.8 * b[0]                    # both actually train
+    for x, y in zip(a, b):
+        assert abs(x - y) <= 0.03 * abs(x) + 0.02, (a, b)
