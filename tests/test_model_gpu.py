@@ -584,3 +584,59 @@ def test_bf16_training_tracks_fp32_training():
     assert a[-1] < 0.8 * a[0] and b[-1] < 0.8 * b[0]                    # both actually train
     for x, y in zip(a, b):
         assert abs(x - y) <= 0.03 * abs(x) + 0.02, (a, b)
+
+
+def test_pipeline_with_rccl_collectives_single_rank_group():
+    """The N>1 code path on one GPU: a 1-rank RCCL process group, BackwardPipeline with force_collective (the all-reduce of
+    every slice really goes through RCCL), fp32 and bf16-compressed gradients, eager and hipGraph-captured.  With one
+    rank the sum is the identity, so the result must equal the plain path (bf16 compression: within bf16 rounding)."""
+    import os
+    import torch.distributed as dist
+    from gst_visdial_amd.optim import FusedAdamW
+    from gst_visdial_amd.pipeline import BackwardPipeline
+    from gst_visdial_amd.graph import GraphedStep
+    s = sc()
+    g = load_npz("tiny_train.npz")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        def run(mode, graphed=False, steps=4):
+            model, params, cfg = s.build_tiny_model("fp32", DEV, seed=3)
+            model.eval()
+            kw = s.golden_batch(g, DEV)
+            opt = FusedAdamW(model, lr=1e-3)
+            if mode != "plain":
+                BackwardPipeline(model.engine, optimizer=opt, chunk_elems=100000, compress=("bf16" if mode == "bf16" else None),
+                                 force_collective=True)
+
+            def step():
+                loss, _ = model(**kw)
+                loss.backward()
+                opt.step()
+                opt.zero_grad()
+                return loss
+
+            fn = step
+            if graphed:
+                for _ in range(2):
+                    step()
+                fn = GraphedStep(step, warmup=0)
+                steps -= 2
+            for _ in range(steps):
+                loss = fn()
+            torch.cuda.synchronize()
+            return loss.item(), model.engine.flat.P.clone()
+
+        l0, p0 = run("plain")
+        l1, p1 = run("fp32")
+        l2, p2 = run("bf16")
+        l3, p3 = run("bf16", graphed=True)
+        assert abs(l0 - l1) < 1e-5 and maxerr(p0, p1) < 1e-6
+        assert abs(l0 - l2) < 5e-3 * max(1.0, abs(l0)) and maxerr(p0, p2) < 5e-3
+        assert abs(l2 - l3) < 1e-6 and maxerr(p2, p3) < 1e-6                # captured == eager, collectives included
+    finally:
+        if created:
+            dist.destroy_process_group()
