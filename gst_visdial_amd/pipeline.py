@@ -42,8 +42,14 @@ class BackwardPipeline(object):
             self.opt.begin_step()
 
     def ready(self, off):
-        """True when the completed region [off, hi) should be emitted now."""
-        return off < self.hi and ((self.hi - off) >= self.chunk or off == 0)
+        """True when the completed region [off, hi) should be emitted now.  `chunk_elems` may be a sequence: the k-th slice
+        waits for chunk_elems[min(k, last)] elements -- large slices first (their all-reduce has the whole rest of backward
+        to hide behind), small ones at the end (the last slice's wgrad + all-reduce + AdamW is the exposed tail)."""
+        if isinstance(self.chunk, (list, tuple)):
+            need = self.chunk[min(len(self.slices), len(self.chunk) - 1)]
+        else:
+            need = self.chunk
+        return off < self.hi and ((self.hi - off) >= need or off == 0)
 
     def run_slice(self, lo, hi):
         """Runs on the auxiliary stream, after the slice's weight-gradient GEMMs and column reductions."""
