@@ -149,6 +149,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    # GSTVD_BENCH_ONE_GPU=1 (validation only): run the multi-rank control flow with every rank on cuda:0 and the collectives
+    # over gloo (RCCL refuses two ranks on one device; gloo cannot be graph-captured, so the step is issued eagerly)
+    one_gpu = bool(os.environ.get("GSTVD_BENCH_ONE_GPU")) and world > 1
+    if one_gpu:
+        local = 0
+        if args.graph == "auto":
+            args.graph = "off"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if rank != 0:                             # only rank 0 reports; keep the other ranks' C-level chatter off the shared stdout
@@ -163,7 +170,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=device)
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     from gst_visdial_amd import ops
