@@ -915,14 +915,16 @@ class Engine(object):
         static = tuple(x.clone() if x is not None else None for x in ins)
         tok_buf = torch.zeros(ins[3].shape[0], dtype=torch.long, device=ins[3].device)
         encode, one_token = self._decode_plan(static, L0, max_seq_len)
-        torch.cuda.synchronize()
+        from .graph import quiesce_before_capture, capture_error_mode
+        quiesce_before_capture()
+        mode = capture_error_mode()
         g_enc = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g_enc):
+        with torch.cuda.graph(g_enc, capture_error_mode=mode):
             encode()
         graphs, outs = [], []
         for t in range(L0 + max_seq_len - 1):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=g_enc.pool()):
+            with torch.cuda.graph(g, pool=g_enc.pool(), capture_error_mode=mode):
                 outs.append(one_token(tok_buf, t))
             graphs.append(g)
 
