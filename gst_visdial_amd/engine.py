@@ -807,7 +807,9 @@ class Engine(object):
         if self.pipe is not None:
             if self.pipe.hi > 0:
                 self._emit(0)
-            self.pipe.end()
+            tail = self.pipe.end()
+            if tail is not None:                       # communication stream (all-reduce + AdamW of the slices): join it here
+                self.main.wait_event(tail)
         if self.aux_busy:
             ev = torch.cuda.Event()
             ev.record(self.aux)

@@ -7,7 +7,8 @@ which -- on the engine's auxiliary stream, i.e. concurrently with the remaining 
     1. the deferred weight-gradient GEMMs of the slice (one grouped launch) and its column reductions,
     2. for N > 1: a RCCL sum all-reduce of G[lo:hi] (one large contiguous collective per slice; xGMI links are
        point to point, so few large messages beat many small ones),
-    3. the fused AdamW update of P[lo:hi] (+ bf16 shadow weights), with the 1/N scale folded in.
+    3. the fused AdamW update of P[lo:hi] (+ bf16 shadow weights), with the 1/N scale folded in;
+    at N > 1 steps 2-3 ride on a dedicated communication stream so that the aux stream can start the next slice.
 
 This is the MI355X-native replacement of nn.DataParallel's per-step parameter broadcast + gradient reduce-add
 (train_gen.py:295,324) and of the serial optimizer.step() (train_gen.py:326-329).  loss = mean over ranks of the
@@ -30,6 +31,9 @@ class BackwardPipeline(object):
         self.collective = self.world > 1 or (force_collective and dist.is_initialized())
         self.hi = None
         self.slices = []
+        self._bufs, self.comm, self.tail_event = {}, None, None
+        import os
+        self.use_comm_stream = os.environ.get("GSTVD_PIPE_COMM", "1") != "0"
         if optimizer is not None:
             optimizer.grad_scale = 1.0 / self.world
         engine.pipe = self
@@ -52,27 +56,72 @@ class BackwardPipeline(object):
         return off < self.hi and ((self.hi - off) >= need or off == 0)
 
     def run_slice(self, lo, hi):
-        """Runs on the auxiliary stream, after the slice's weight-gradient GEMMs and column reductions."""
+        """Runs on the auxiliary stream, after the slice's weight-gradient GEMMs and column reductions.
+
+        With a collective the rest of the slice's life -- compression cast, all-reduce, AdamW -- moves to a dedicated
+        communication stream that forks from the aux stream here and is joined into the stream backward started on only at
+        the end of backward (`end()` returns the event): the aux stream goes straight on to the next slice's weight
+        gradients while this slice's message travels.  (Joining it back into the aux stream instead segfaults
+        hipStreamEndCapture on this stack: a forked stream may only be joined into the capture's origin stream.)"""
         flat = self.engine.flat
         self.slices.append((lo, hi))
-        reduced_bf16 = None
-        if self.collective:
-            sl = flat.G[lo:hi]
+        sl = flat.G[lo:hi]
+        if not self.collective:
+            self._update(lo, hi, None)
+        elif not sl.is_cuda or not self.use_comm_stream:       # host tensors (gloo tests) / in-line variant
+            reduced = None
             if self.compress == "bf16":
-                from . import ops
-                tmp = torch.empty(hi - lo, dtype=torch.bfloat16, device=sl.device)
-                ops.cast(sl, tmp)
-                dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group)
-                if self.opt is None or self.keep_grads:
-                    ops.cast(tmp, sl)
+                if sl.is_cuda:
+                    from . import ops
+                    reduced = torch.empty(hi - lo, dtype=torch.bfloat16, device=sl.device)
+                    ops.cast(sl, reduced)
                 else:
-                    reduced_bf16 = tmp
+                    reduced = sl.to(torch.bfloat16)
+                dist.all_reduce(reduced, op=dist.ReduceOp.SUM, group=self.group)
             else:
                 dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group)
-        if self.opt is not None:
-            self.opt.apply_range(lo, hi, grad_bf16=reduced_bf16)
+            self._update(lo, hi, reduced)
+        else:
+            from . import ops
+            if self.comm is None:
+                self.comm = torch.cuda.Stream(device=sl.device)
+                self._tick = torch.zeros(1, device=sl.device)
+            reduced = None
+            if self.compress == "bf16":
+                reduced = self._bufs.get((lo, hi))             # persistent: no allocator traffic across streams
+                if reduced is None:
+                    reduced = self._bufs[(lo, hi)] = torch.empty(hi - lo, dtype=torch.bfloat16, device=sl.device)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.comm.wait_event(ev)
+            with torch.cuda.stream(self.comm):
+                # work of our own precedes the collective on this stream (the compression cast, or a 4-byte memset): a
+                # stream that has only waited on a captured event does not report itself as capturing yet
+                if reduced is not None:
+                    ops.cast(sl, reduced)
+                    dist.all_reduce(reduced, op=dist.ReduceOp.SUM, group=self.group)
+                else:
+                    self._tick.zero_()
+                    dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group)
+                self._update(lo, hi, reduced)
+                self.tail_event = torch.cuda.Event()
+                self.tail_event.record(self.comm)
         self.hi = lo
 
+    def _update(self, lo, hi, reduced):
+        if reduced is not None and (self.opt is None or self.keep_grads):
+            if reduced.is_cuda:
+                from . import ops
+                ops.cast(reduced, self.engine.flat.G[lo:hi])
+            else:
+                self.engine.flat.G[lo:hi].copy_(reduced)
+            reduced = None
+        if self.opt is not None:
+            self.opt.apply_range(lo, hi, grad_bf16=reduced)
+
     def end(self):
+        """End of backward.  Returns the event the caller's stream must wait on (the communication stream's last work) or None."""
         if self.opt is not None:
             self.opt._applied_in_backward = True
+        ev, self.tail_event = self.tail_event, None
+        return ev
