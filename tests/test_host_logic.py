@@ -238,3 +238,40 @@ def test_bench_synthetic_rows_follow_the_survey_generator():
         assert lab[r, n - 1] == 102 and (lab[r, n:] == 0).all()
         assert torch.equal(dec[r, 1:n], lab[r, :n - 1]) and (dec[r, n:] == 0).all()
         assert dmask[r].sum() >= n
+
+
+def _append_reference_semantics(ctx, ctx_len, new, sep, seg=None):
+    """Per-row restatement of what generate.py:145-158 / 203-218 do (slice assignment; on a size mismatch a lone [SEP])."""
+    B, T = ctx.shape
+    bad = []
+    lens = (new != 0).sum(-1)
+    for b in range(B):
+        n = int(lens[b]); start = int(ctx_len[b]); end = start + n
+        if end <= T:
+            ctx[b, start:end] = new[b, :n]
+        else:
+            ctx[b, start:start + 1] = torch.tensor([sep])
+            n = 1; end = start + 1; bad.append(b)
+        if seg is not None:
+            seg[b, start:end] = 1
+        ctx_len[b] += n
+    return bad
+
+
+def test_append_to_context_matches_per_row_reference_semantics():
+    from gst_visdial_amd.generate import append_to_context
+    g = torch.Generator().manual_seed(3)
+    B, T, U = 9, 40, 18
+    for trial in range(20):
+        ctx_len = torch.randint(5, T - 1, (B,), generator=g)
+        ctx = torch.randint(5, 300, (B, T), generator=g) * (torch.arange(T)[None] < ctx_len[:, None])
+        n = torch.randint(0, U + 1, (B,), generator=g)
+        new = torch.randint(5, 300, (B, U), generator=g) * (torch.arange(U)[None] < n[:, None])
+        seg = torch.zeros(B, T, dtype=torch.long)
+        c1, l1, s1 = ctx.clone(), ctx_len.clone(), seg.clone()
+        c2, l2, s2 = ctx.clone(), ctx_len.clone(), seg.clone()
+        bad_ref = _append_reference_semantics(c1, l1, new, 102, s1)
+        n_eff, bad = append_to_context(c2, l2, new, 102, segments=s2, segment_value=1)
+        assert torch.equal(c1, c2) and torch.equal(l1, l2) and torch.equal(s1, s2)
+        assert bad.tolist() == bad_ref
+        assert torch.equal(n_eff, l2 - ctx_len)

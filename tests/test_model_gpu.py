@@ -640,3 +640,63 @@ def test_pipeline_with_rccl_collectives_single_rank_group():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_dialog_round_perplexity_and_context_update():
+    """gst_visdial_amd.generate (generate.py:122-228): sample a question, append it, sample an answer, score it with the
+    answerer ("ppl trick"), append it with segment 1.  The perplexity equals the oracle's on the same context and answer;
+    the context grows by exactly the sampled tokens; a row that would overflow receives a lone [SEP]."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import vd_oracle as O
+    from gst_visdial_amd.generate import dialog_round, append_to_context, answer_perplexity
+    s = sc()
+    model, params, cfg = s.build_tiny_model("fp32", DEV, mode="cc12m_gen")
+    model.eval()
+    g = load_npz("tiny_train.npz")
+    kw = s.golden_batch(g, DEV)
+    B, T = kw["enc_input_ids"].shape
+
+    def fresh_state():
+        ids = kw["enc_input_ids"].clone()
+        ids[:, T // 2:] = 0                                 # leave room for a round ...
+        ids[-1] = kw["enc_input_ids"][-1]
+        ids[-1, T - 3:] = 0                                 # ... except in the last row: its question overflows
+        ids[-1, :T - 3] = ids[-1, :T - 3].clamp(min=5)
+        seg = kw["enc_segments"].clone() * (ids != 0)
+        return dict(enc_image_features=kw["enc_image_features"], enc_image_spatials=kw["enc_image_spatials"],
+                    enc_image_mask=kw["enc_image_mask"], enc_input_ids=ids, enc_segments=seg,
+                    enc_input_len=(ids != 0).sum(-1), dec_input_ids=torch.full((B, 1), 101, dtype=torch.long, device=DEV),
+                    dec_attention_mask=torch.ones(B, 1, device=DEV))
+
+    # ---- the whole round
+    state = fresh_state()
+    len0 = state["enc_input_len"].clone()
+    torch.manual_seed(0)
+    ques, ans, ppl, bad = dialog_round(model, model, state)
+    assert ques.shape == ans.shape == (B, 18) and ppl.shape == (B,) and torch.isfinite(ppl).all() and (ppl > 1).all()
+    assert params["mode"] == "cc12m_gen"                    # the mode flip of the ppl pass is undone
+    assert (B - 1) in bad.tolist()                          # the nearly full row got a lone [SEP]
+    assert (state["enc_input_len"] > len0).all() and (state["enc_input_len"] <= T).all()
+    assert torch.equal((state["enc_input_ids"] != 0).sum(-1), state["enc_input_len"])
+    # ---- the perplexity pass against the oracle, step by step with the same pieces
+    state = fresh_state()
+    enc = lambda: dict(enc_image_features=state["enc_image_features"], enc_image_spatials=state["enc_image_spatials"],
+                       enc_image_mask=state["enc_image_mask"], enc_input_ids=state["enc_input_ids"],
+                       enc_segments=state["enc_segments"], enc_attention_mask=(state["enc_input_ids"] != 0).float())
+    torch.manual_seed(1)
+    q = model(dec_input_ids=state["dec_input_ids"], dec_attention_mask=state["dec_attention_mask"], temperature=0.7, top_k=7,
+              top_p=0.0, ngram_blocking_size=4, **enc())
+    append_to_context(state["enc_input_ids"], state["enc_input_len"], q, 102)
+    a = model(dec_input_ids=state["dec_input_ids"], dec_attention_mask=state["dec_attention_mask"], temperature=0.7, top_k=7,
+              top_p=0.0, ngram_blocking_size=0, **enc())
+    sampled = a.clone()
+    got, ans_len = answer_perplexity(model, enc(), a)
+    assert not torch.equal(a, sampled) or not (sampled == 102).any()        # [SEP] -> [PAD] happened in place
+    cpu = {k: v.cpu() for k, v in enc().items()}
+    cpu.update(dec_input_ids=sampled.cpu().clone(), dec_attention_mask=(sampled != 0).float().cpu())
+    out = O.model_forward(load_npz("tiny_state.npz"), cfg["enc"], cfg["dec"], cpu, loss_reduction=False)
+    ref_len = (cpu["dec_input_ids"] != 0).sum(-1)           # after the oracle's own [SEP] -> [PAD] mutation
+    assert torch.equal(ref_len, ans_len.cpu())
+    ref_ppl = torch.exp(out["loss"].reshape(B, 18).sum(-1) / ref_len)
+    assert maxerr(got, ref_ppl) <= 1e-3 * ref_ppl.max().item()
