@@ -1,8 +1,8 @@
 """Token-id side of the sampling decode (utils/decoding_utils.py:4-77, models/visual_dialog_model.py:113-119).
 
 Integer / index work that must be bit-exact with the reference; it runs as torch index plumbing on whatever
-device the logits live on (the n-gram table is built on the host from one transfer per call, like the
-reference's `.tolist()` loops but without the per-row synchronisation)."""
+device the logits live on, without host round trips (the reference's n-gram ban walks Python dictionaries built from
+`.tolist()` every step)."""
 import torch
 import torch.nn.functional as F
 
@@ -28,7 +28,33 @@ def batch_top_k_top_p_sampling(logits, top_k=0, top_p=0.0, filter_value=NEG_INF)
 def batch_ngram_blocking(logits, enc_input_ids, dec_input_ids, ngram_size=0, filter_value=NEG_INF,
                          special_token_ids=(0, 100, 101, 102, 103)):
     """Ban every token that would complete an n-gram already present in `enc_input_ids` (n-grams that touch a
-    special token are ignored)."""
+    special token are ignored).  Vectorised on the logits' device -- no host round trip per decode step; same bans as
+    the reference's per-row dictionary loops (`_ngram_blocking_loop` below restates those, tests compare the two)."""
+    assert logits.dim() == 2
+    cur = dec_input_ids.shape[-1]
+    T = enc_input_ids.shape[-1]
+    n = ngram_size
+    if n <= 0 or cur < n - 1 or T < n:      # (python slice semantics of the reference: a short prefix never matches)
+        return logits
+    dev = logits.device
+    hist = enc_input_ids.to(dev)
+    win = hist.unfold(1, n, 1)                                              # [B, T-n+1, n] every n-gram of the history
+    special = torch.tensor(special_token_ids, device=dev, dtype=hist.dtype)
+    clean = ~(win.unsqueeze(-1) == special).any(-1).any(-1)                 # n-grams without a special token
+    if n > 1:
+        prefix = dec_input_ids.to(dev)[:, cur - (n - 1):cur]                # the last n-1 generated tokens
+        hit = (win[..., :n - 1] == prefix[:, None, :]).all(-1) & clean
+    else:
+        hit = clean
+    rows = torch.arange(hist.shape[0], device=dev)[:, None].expand_as(hit)
+    banned = torch.zeros_like(logits, dtype=torch.bool)
+    banned[rows[hit], win[..., n - 1][hit]] = True
+    return logits.masked_fill(banned, filter_value)
+
+
+def _ngram_blocking_loop(logits, enc_input_ids, dec_input_ids, ngram_size=0, filter_value=NEG_INF,
+                         special_token_ids=(0, 100, 101, 102, 103)):
+    """Per-row restatement of utils/decoding_utils.py:34-77 (host loops); kept as the checker of the vectorised form."""
     assert logits.dim() == 2
     if ngram_size <= 0:
         return logits

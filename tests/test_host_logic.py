@@ -275,3 +275,22 @@ def test_append_to_context_matches_per_row_reference_semantics():
         assert torch.equal(c1, c2) and torch.equal(l1, l2) and torch.equal(s1, s2)
         assert bad.tolist() == bad_ref
         assert torch.equal(n_eff, l2 - ctx_len)
+
+
+def test_vectorised_ngram_blocking_equals_the_reference_loops():
+    from gst_visdial_amd.decoding import batch_ngram_blocking, _ngram_blocking_loop
+    g = torch.Generator().manual_seed(5)
+    V = 40                                                   # small vocabulary: plenty of repeated n-grams
+    for trial in range(60):
+        B, T = 4, int(torch.randint(3, 30, (1,), generator=g))
+        n = int(torch.randint(0, 6, (1,), generator=g))
+        cur = int(torch.randint(1, 12, (1,), generator=g))
+        hist = torch.randint(0, V, (B, T), generator=g)
+        hist[torch.rand(B, T, generator=g) < 0.1] = 102      # sprinkle special tokens
+        dec = torch.randint(0, V, (B, cur), generator=g)
+        if T >= 3 and cur >= 2:                              # force some real matches
+            dec[0, -2:] = hist[0, 1:3]
+        logits = torch.randn(B, V + 70, generator=g)
+        a = batch_ngram_blocking(logits.clone(), hist, dec, ngram_size=n)
+        b = _ngram_blocking_loop(logits.clone(), hist, dec, ngram_size=n)
+        assert torch.equal(a, b), (trial, n, cur, T)
