@@ -53,4 +53,7 @@ with torch.no_grad():
     tg = timeit(lambda: model(**kw), n=5, warm=2)
     out["sampling_decode_16rows_18steps"] = {"eager_ms": round(te * 1e3, 2), "hipgraph_ms": round(tg * 1e3, 2),
                                              "rows_per_s_hipgraph": round(16 / tg, 1), "speedup": round(te / tg, 2)}
+    kw["ngram_blocking_size"] = 4                             # question generation (generate.py:141): n-gram ban on the device
+    tn = timeit(lambda: model(**kw), n=5, warm=2)
+    out["sampling_decode_16rows_18steps_ngram4"] = {"hipgraph_ms": round(tn * 1e3, 2), "rows_per_s_hipgraph": round(16 / tn, 1)}
 print(json.dumps(out))
