@@ -173,6 +173,8 @@ def main():
         if one_gpu:
             dist.init_process_group("gloo")
         else:
+            from gst_visdial_amd.graph import enable_watchdog_introspection
+            enable_watchdog_introspection()      # lets the capture wait until c10d's watchdog has retired the warm-up collectives
             dist.init_process_group("nccl", device_id=device)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
@@ -203,12 +205,24 @@ def main():
     pipe = None if args.no_pipeline else BackwardPipeline(model.engine, optimizer=opt, chunk_elems=chunk_elems,
                                                           compress=compress, force_collective=force_dist)
 
-    def step():
+    def device_step():
+        """Everything of a train step that is device work -- the part that is captured into the hipGraph."""
         loss, _ = model(**batch)
         loss.backward()          # includes the pipelined all-reduce + AdamW
         opt.step()               # no-op marker: the update was applied during backward
-        opt.scheduler_step()
         opt.zero_grad()
+        return loss
+
+    def host_step_end():
+        """Host side of train_gen.py:329 (scheduler.step()): stays OUTSIDE the captured function, or it would run once at
+        capture time and never again -- the schedule position advances every step and the device learning-rate table is
+        refreshed (a 2 KB pinned-memory copy) whenever the value changed."""
+        opt.scheduler_step()
+        opt.upload_lr()
+
+    def step():
+        loss = device_step()
+        host_step_end()
         return loss
 
     def barrier():
@@ -230,16 +244,35 @@ def main():
         # same kernels, same work, no host in the loop.  Device-resident state (dropout offset, AdamW step counter)
         # advances inside the graph.
         from gst_visdial_amd.graph import GraphedStep
+        capture_error = None
         try:
-            step = GraphedStep(eager_step, warmup=0)
-            for _ in range(args.warmup):
-                loss = step()
-        except Exception as ex:          # noqa: BLE001 -- any capture failure: keep going eagerly
-            sys.stderr.write("bench: hipGraph capture failed (%s: %s); falling back to eager issue\n" % (type(ex).__name__, ex))
+            replay = GraphedStep(device_step, warmup=0)
+        except Exception as ex:          # noqa: BLE001
+            capture_error = "%s: %s" % (type(ex).__name__, ex)
             torch.cuda.synchronize()
+        if world > 1 or force_dist:
+            # every rank must take the same decision: a rank that replays while another issues eagerly would mismatch
+            # collective counts and hang.  And at N>1 the eager path is host bound (~26 ms of launches for ~15 ms of GPU work),
+            # so a silent fall-back would report a throughput that is not the product's: fail loudly instead.
+            import torch.distributed as dist
+            ok = torch.tensor([0.0 if capture_error else 1.0], device=device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok.item()) < 1.0:
+                sys.stderr.write("bench: hipGraph capture of the train step failed on %s (%s); refusing to time the host-bound "
+                                 "eager path at N>1 (use --graph off to measure it on purpose)\n"
+                                 % ("this rank" if capture_error else "another rank", capture_error))
+                dist.destroy_process_group()
+                sys.exit(3)
+        if capture_error is None:
+            def step():                  # noqa: F811
+                loss = replay()
+                host_step_end()
+                return loss
+        else:
+            sys.stderr.write("bench: hipGraph capture failed (%s); falling back to eager issue\n" % capture_error)
             step, use_graph = eager_step, False
-            for _ in range(args.warmup):
-                loss = step()
+        for _ in range(args.warmup):
+            loss = step()
     barrier()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -344,7 +377,9 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
                "data": "synthetic (random-init weights, synthetic 10-round-dialog rows, features resident in HBM)",
                "config": {"workload": "enc_dec_a train step (fwd+loss+bwd+allreduce+AdamW, dropout on), %d rows/GPU, "
-                                      "seq_len %d, 37x2048 region features, answer len 25" % (B, T),
+                                      "seq_len %d, 37x2048 region features, answer len 25 [%s]"
+                                      % (B, T, "BASELINE configs[1] per-GPU shape" if B == 16 else
+                                         "BASELINE configs[2] per-rank shape (global 80 at 8 GPUs)" if B == 10 else "custom rows/GPU"),
                           "global_batch": B * world, "seq_len": T, "parallelism": "dp%d" % world,
                           "gpu_ms_per_step_events": round(e0.elapsed_time(e1) / args.steps, 3), "eager_host_issue_ms_per_step": round(host_ms, 3), "hip_graph": bool(use_graph),
                           "final_loss": round(final_loss, 4)},

@@ -2,21 +2,37 @@
 
 A checkpoint is `torch.save({'model_state_dict', 'scheduler_state_dict', 'optimizer_state_dict', 'iter_id'})`; the model
 part is `EncoderDecoderModel.state_dict()` with the reference's 861 keys, so files written by the reference load
-here and files written here load there (eval / generate only read 'model_state_dict').  The optimizer part holds the
-flat AdamW moments of `FusedAdamW` (the reference's per-tensor state is not interchangeable: its optimizer is built
-before the embedding aliasing and carries orphaned parameters).
+here and files written here load there.  The optimizer part is either the flat AdamW moments of `FusedAdamW` (compact:
+two tensors) or, with `reference_format=True`, the reference's own per-tensor `optimizer.state_dict()` layout (one param
+group per tensor in the order train_gen.py:209-245 builds them, incl. the slots of the decoder embeddings orphaned by the
+aliasing: optim.reference_param_index) -- so `-continue` (train_gen.py:254-276) works in both directions.  Loading detects
+the layout.
 """
 import torch
 
 
-def save_checkpoint(path, model, optimizer=None, iter_id=0):
+def _cpu(o):
+    if torch.is_tensor(o):
+        return o.detach().cpu()
+    if isinstance(o, dict):
+        return {k: _cpu(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return type(o)(_cpu(v) for v in o)
+    return o
+
+
+def save_checkpoint(path, model, optimizer=None, iter_id=0, reference_format=False):
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     ck = {"model_state_dict": sd, "iter_id": int(iter_id), "scheduler_state_dict": {}, "optimizer_state_dict": {}}
     if optimizer is not None:
-        st = optimizer.state_dict()
-        ck["optimizer_state_dict"] = {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in st.items()}
-        ck["scheduler_state_dict"] = {"last_epoch": optimizer.sched_step, "warmup_steps": optimizer.warmup_steps,
-                                      "t_total": optimizer.t_total, "min_lr": optimizer.min_lr}
+        st = optimizer.export_reference_state() if reference_format else optimizer.state_dict()
+        ck["optimizer_state_dict"] = _cpu(st)
+        # the keys utils/optim_utils.py's _LRScheduler subclass saves that matter for a resume
+        ck["scheduler_state_dict"] = {"last_epoch": optimizer.sched_step, "_step_count": optimizer.sched_step + 1,
+                                      "warmup_steps": optimizer.warmup_steps, "t_total": optimizer.t_total,
+                                      "min_lr": optimizer.min_lr}
+        if reference_format:
+            ck["scheduler_state_dict"]["base_lrs"] = [g["initial_lr"] for g in st["param_groups"]]
     torch.save(ck, path)
 
 
@@ -32,11 +48,14 @@ def load_checkpoint(path, model, optimizer=None, cont=True, map_location="cpu"):
         model.load_state_dict(own)
         if optimizer is not None and ck.get("optimizer_state_dict"):
             st = ck["optimizer_state_dict"]
-            if "m" in st:
-                optimizer.load_state_dict(st)
             sch = ck.get("scheduler_state_dict") or {}
             if "last_epoch" in sch:
                 optimizer.sched_step = int(sch["last_epoch"])
+            if "m" in st:
+                st = dict(st, sched_step=optimizer.sched_step if "last_epoch" in sch else st.get("sched_step", 0))
+                optimizer.load_state_dict(st)
+            elif "state" in st and "param_groups" in st:          # written by the reference (or reference_format=True)
+                optimizer.import_reference_state(st)
         return int(ck.get("iter_id", 0)) if isinstance(ck, dict) else 0
     enc = model.encoder
     own = enc.state_dict()

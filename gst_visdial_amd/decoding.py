@@ -83,3 +83,14 @@ def pad_after_eos(sequence, eos_token_id, pad_token_id):
     eq = (sequence == eos_token_id).long()
     after = (torch.cumsum(eq, dim=1) - eq) > 0
     return sequence.masked_fill(after, pad_token_id)
+
+
+def draw_from_uniform(prob, u):
+    """Inverse-CDF draw: token = first index whose cumulative probability reaches u * total, u [B] in (0, 1).
+    The stand-in for torch.multinomial(prob, 1) (models/visual_dialog_model.py:104-108) when the caller supplies the
+    randomness: multinomial's stream differs between devices, this rule does not, so sampled ids can be compared with the
+    reference run under the same uniforms (oracle/make_golden_r2.py patches the reference's multinomial with this rule)."""
+    c = torch.cumsum(prob.float(), dim=-1)
+    x = u.to(c.device, torch.float32).reshape(-1, 1) * c[:, -1:]
+    idx = (c < x).sum(-1, keepdim=True)
+    return idx.clamp_(max=prob.shape[-1] - 1)

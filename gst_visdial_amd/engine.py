@@ -23,6 +23,8 @@ the C ABI (`ops`).  Design points:
 Numerics: precision 'fp32' runs every GEMM on the exact-fp32 MFMA (parity gate: logits within 1e-4 of the
 oracle); 'bf16' stores activations/weights in bf16 with fp32 accumulation and fp32 LN/softmax/CE statistics.
 """
+import weakref
+
 import torch
 
 from . import ops
@@ -270,9 +272,24 @@ class FlatParams(object):
         return buf[off:off + n].view(shape)
 
 
+_DEVICE_STREAMS = {}
+
+
+def device_streams(device):
+    """ONE (vision, auxiliary) stream pair per device for every engine of the process.  torch hands out pool streams
+    round-robin over 32 slots; a pair per Engine meant that after ~16 models (a test session, a checkpoint sweep) new
+    engines aliased older engines' streams and the capture stream."""
+    key = torch.device(device).index or 0
+    if key not in _DEVICE_STREAMS:
+        _DEVICE_STREAMS[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+    return _DEVICE_STREAMS[key]
+
+
 class Engine(object):
     def __init__(self, model):
-        self.model = model
+        # weak: the model owns the engine, not the other way round -- no reference cycle, so dropping the model frees the
+        # flat buffers, the arena and any captured decode sessions by reference counting, not at some later GC pass
+        self._model_ref = weakref.ref(model)
         self.enc_cfg, self.dec_cfg = model.encoder.config, model.decoder.config
         prec = model.params.get("amd_precision", "bf16")
         if prec not in ("bf16", "fp32"):
@@ -283,6 +300,7 @@ class Engine(object):
         self.arena = None
         self.rng = None
         self._decode_sessions = {}
+        self._last_decode = None
         self.anchor = None
         self.grad_hook = None          # callable(offset): every gradient at flat offset >= `offset` is final
         self.pipe = None               # BackwardPipeline (pipeline.py): slice-wise wgrad / all-reduce / AdamW on the aux stream
@@ -292,6 +310,17 @@ class Engine(object):
         self._validate = True
         self.use_streams = bool(model.params.get("amd_streams", True))
         self.tag = "t"
+
+    @property
+    def model(self):
+        m = self._model_ref()
+        if m is None:
+            raise GstvdError("the EncoderDecoderModel this engine belonged to is gone")
+        return m
+
+    def close(self):
+        """Drop captured decode sessions (hipGraphs + their private pool) now."""
+        self._decode_sessions.clear()
 
     # ------------------------------------------------------------------------------------------ setup
     def prepare(self, device):
@@ -307,12 +336,13 @@ class Engine(object):
         if not self.flat.is_materialized() or self.flat.device != device:
             self.flat.materialize(device)
             self._bind_views()
+            self._decode_sessions.clear()         # captured graphs address the old buffers
         if self.arena is None or self.arena.device != device:
+            self._decode_sessions.clear()
             self.arena = Arena(device)
             self.rng = ops.Rng(device, seed=int(self.model.params.get("amd_seed", 0)))
             self.anchor = torch.zeros(1, device=device, requires_grad=True)
-            self.side = torch.cuda.Stream(device=device)
-            self.aux = torch.cuda.Stream(device=device)
+            self.side, self.aux = device_streams(device)
             self.aux_busy = False
             self.colsums = ops.ColsumBatch(device)
             self.wgrads = ops.GemmGroup(device, a_km=True, b_km=True)
@@ -769,7 +799,7 @@ class Engine(object):
             loss = _StepFn.apply(self.anchor, feats if I["feats_grad"] else None, self, st, loss_raw)
             return loss, lv
         loss = stats[2].clone() if loss_reduction else row_loss.clone()
-        return loss, lv.float()
+        return loss, lv.to(torch.float32, copy=True)      # a copy: the arena is rewound by the next engine call
 
     def backward(self, st, gloss):
         """Replay the tape: fills the flat gradient buffer, assigns `.grad` views, returns d loss / d image features."""
@@ -908,7 +938,7 @@ class Engine(object):
                 y = self.ln(fo, y2, p + ".ln3.w", p + ".ln3.b", H, 0.0, None, eps)
             return self.lin(y, "lm.w", "lm.b", Vp, H).t[:, :V].float()
 
-        return encode, one_token
+        return encode, one_token, st
 
     def _decode_session(self, ins, L0, max_seq_len):
         """hipGraph form of a decode call (generate.py's loop calls sample() with the same shapes batch after batch):
@@ -916,19 +946,18 @@ class Engine(object):
         Returns (refresh(ins), run_encode(), run_token(tok, t) -> logits)."""
         static = tuple(x.clone() if x is not None else None for x in ins)
         tok_buf = torch.zeros(ins[3].shape[0], dtype=torch.long, device=ins[3].device)
-        encode, one_token = self._decode_plan(static, L0, max_seq_len)
-        from .graph import quiesce_before_capture, capture_error_mode
-        quiesce_before_capture()
-        mode = capture_error_mode()
-        g_enc = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g_enc, capture_error_mode=mode):
-            encode()
-        graphs, outs = [], []
-        for t in range(L0 + max_seq_len - 1):
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=g_enc.pool(), capture_error_mode=mode):
-                outs.append(one_token(tok_buf, t))
-            graphs.append(g)
+        encode, one_token, st = self._decode_plan(static, L0, max_seq_len)
+        from .graph import capture, gc_quiet
+        with gc_quiet():
+            g_enc = torch.cuda.CUDAGraph()
+            with capture(g_enc):
+                encode()
+            graphs, outs = [], []
+            for t in range(L0 + max_seq_len - 1):
+                g = torch.cuda.CUDAGraph()
+                with capture(g, pool=g_enc.pool(), quiesce=False):
+                    outs.append(one_token(tok_buf, t))
+                graphs.append(g)
 
         def refresh(new):
             for dst, src in zip(static, new):
@@ -940,11 +969,11 @@ class Engine(object):
             graphs[t].replay()
             return outs[t]
 
-        return refresh, g_enc.replay, run_token
+        return refresh, g_enc.replay, run_token, st
 
     @torch.no_grad()
     def sample(self, feats, loc, img_mask, ids, segs, att_mask, dec_ids, temperature=1.0, top_k=0, top_p=0.0,
-               ngram_blocking_size=0, max_seq_len=18, **_):
+               ngram_blocking_size=0, max_seq_len=18, uniforms=None, **_):
         """models/visual_dialog_model.py:74-120: 18 sampling steps (temperature, n-gram blocking, top-k / top-p, multinomial
         draw, [PAD] after the first [SEP]).  The reference re-runs the whole decoder on the growing prefix and re-projects
         the cross-attention K/V of all 37+T encoder states in all 12 layers at every step (use_cache=False); here the
@@ -952,7 +981,10 @@ class Engine(object):
         appending its self-attention K/V to a [B, Umax, H] cache per layer.  Same arithmetic, O(U) instead of O(U^2).
         From the second call with the same shapes on (params['amd_decode_graph'], default on) the device work is replayed
         from captured hipGraphs (one for the encoder side, one per decoder position): ~2500 launches per call leave the host.
-        Token-id work (filters, n-gram ban, EOS fill) is integer-exact torch / host plumbing (decoding.py)."""
+        Token-id work (filters, n-gram ban, EOS fill) is integer-exact torch / host plumbing (decoding.py).
+        `uniforms` [max_seq_len, B] in (0, 1): draw token t by inverse CDF from uniforms[t] on the device instead of
+        torch.multinomial (whose stream is device specific) -- the same rule the oracle applies to the reference, so sampled
+        ids can be compared under real sampling."""
         from . import decoding
         dc = self.dec_cfg
         if segs is None:
@@ -961,12 +993,15 @@ class Engine(object):
         L0 = dec_ids.shape[1]
         sig = (L0, max_seq_len) + tuple((tuple(x.shape), x.dtype) if x is not None else None for x in ins)
         use_graph = bool(self.model.params.get("amd_decode_graph", True))
+        # parameters edited since the last call (load_state_dict, an optimizer step): the captured graphs read the flat
+        # buffers / bf16 shadow, so bring those up to date OUTSIDE the graphs; a re-materialised buffer drops the sessions
+        self.prepare(ids.device)
         sess = self._decode_sessions.get(sig) if use_graph else None
         if sess is not None:
-            refresh, run_encode, run_token = sess
+            refresh, run_encode, run_token, dst = sess
             refresh(ins)
         else:
-            run_encode, run_token = self._decode_plan(ins, L0, max_seq_len)
+            run_encode, run_token, dst = self._decode_plan(ins, L0, max_seq_len)
         run_encode()
         hist = ids * (segs == 0).long()
         cur, seq = dec_ids, []
@@ -977,10 +1012,14 @@ class Engine(object):
             last = logits / temperature
             last = decoding.batch_ngram_blocking(last, hist, cur, ngram_size=ngram_blocking_size)
             last = decoding.batch_top_k_top_p_sampling(last, top_k=top_k, top_p=top_p)
-            nxt = torch.multinomial(torch.softmax(last, dim=-1), 1)
+            prob = torch.softmax(last, dim=-1)
+            nxt = torch.multinomial(prob, 1) if uniforms is None else decoding.draw_from_uniform(prob, uniforms[len(seq)])
             cur = torch.cat((cur, nxt), dim=-1)
             seq.append(nxt)
         self.last = dict(decode_logits=logits)            # last position's raw logits (tests / debugging)
+        # the encoder side of this call (cross-attention K/V of all layers, masks) stays valid in the arena until the next
+        # engine call: `rescore_sampled` scores the sampled answer against it without a second encoder pass
+        self._last_decode = (dst, ids.shape[0], self.arena)
         out = decoding.pad_after_eos(torch.cat(seq, 1), dc.eos_token_id, dc.pad_token_id)
         if use_graph and sess is None:
             # first call with these shapes ran eagerly (it also initialised every lazily built table / attribute / arena
@@ -989,6 +1028,38 @@ class Engine(object):
                 self._decode_sessions.clear()
             self._decode_sessions[sig] = self._decode_session(ins, L0, max_seq_len)
         return out
+
+
+    @torch.no_grad()
+    def rescore_sampled(self, dec_ids, dec_mask=None, loss_reduction=False):
+        """The "ppl trick" of generate.py:183-211 fused onto the decode call that produced the answer: ONE teacher-forced
+        decoder pass over `dec_ids` against the encoder states / cross-attention K/V that the last `sample()` call left in
+        the arena (same context by construction: the answer was sampled from it) -- no second encoder run, no second K/V
+        projection.  Same conventions as the reference's labels=None branch (visual_dialog_decoder.py:53-57): labels are
+        the ids shifted left, `dec_ids` has [SEP] -> [PAD] in place.  Returns (loss, logits) like `step`."""
+        ld = getattr(self, "_last_decode", None)
+        if ld is None or ld[2] is not self.arena or ld[1] != dec_ids.shape[0]:
+            raise GstvdError("rescore_sampled: no decode state of a matching sample() call to reuse")
+        st = ld[0]
+        dc = self.dec_cfg
+        self.arena.rewind(st["mark"])
+        self.tape, self.rec, self.tag, self.train = [], False, "t", False
+        self.main = torch.cuda.current_stream()
+        labels = dec_ids.new_zeros(dec_ids.shape)
+        labels[:, :-1] = dec_ids[:, 1:].clone()
+        dec_ids.masked_fill_(dec_ids == dc.eos_token_id, dc.pad_token_id)
+        I = dict(st["I"])
+        Bn, U, V = I["B"], dec_ids.shape[1], dc.vocab_size
+        I["U"] = U
+        I["dec_ids"] = dec_ids.contiguous().view(-1)
+        I["dmask"] = dec_mask.float().contiguous() if dec_mask is not None else None
+        _, logits = self.decoder(None, I, kv=st["kv"])
+        Md = Bn * U
+        row_loss, lse, stats = self.vec(Md), self.vec(Md), self.vec(4)
+        ops.ce_fwd(logits.t, labels.contiguous().view(-1), Md, V, row_loss, lse, stats, ignore_index=dc.pad_token_id)
+        self._last_decode = None                  # the decode scratch behind the mark has been overwritten
+        loss = stats[2].clone() if loss_reduction else row_loss.clone()
+        return loss, logits.t.view(Bn, U, self.flat.Vp)[:, :, :V].to(torch.float32, copy=True)
 
 
 class _StepFn(torch.autograd.Function):

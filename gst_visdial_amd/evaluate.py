@@ -13,7 +13,12 @@ def score_batch(model, batch, device, rounds_per_call=20):
     ids = batch["enc_input_ids"]
     B, R_, O = ids.shape[0], ids.shape[1], ids.shape[2]
     T, U = ids.shape[-1], batch["dec_input_ids"].shape[-1]
-    # the `options` rows of a round carry the same context: take option 0 as the round's encoder input
+    seg, att = batch["enc_segments"], batch["enc_att_mask"]
+    # the `options` rows of a round normally carry the same context (dataloader_visdial_gen.py:379-388 encodes it once per
+    # option): then option 0 is the round's encoder input.  Checked, not assumed -- e.g. attack='random_token' masks each
+    # option's copy differently -- and otherwise every option row is scored against its own context (group = 1)
+    if not (bool((ids == ids[:, :, :1]).all()) and bool((seg == seg[:, :, :1]).all()) and bool((att == att[:, :, :1]).all())):
+        return _score_batch_per_row(model, batch, device, rounds_per_call)
     enc_ids = ids[:, :, 0].reshape(B * R_, T)
     enc_seg = batch["enc_segments"][:, :, 0].reshape(B * R_, T)
     enc_att = batch["enc_att_mask"][:, :, 0].reshape(B * R_, T)
@@ -29,6 +34,26 @@ def score_batch(model, batch, device, rounds_per_call=20):
                                     enc_seg[e].to(device), enc_att[e].to(device), dec_ids[e].reshape(-1, U).to(device),
                                     dec_att[e].reshape(-1, U).to(device), O)
         out.append(sc)
+    return torch.cat(out).view(B, R_, O)
+
+
+def _score_batch_per_row(model, batch, device, rounds_per_call):
+    """evaluate_gen.py:45-106 literally: every [dialog, round, option] row through encoder and decoder."""
+    ids = batch["enc_input_ids"]
+    B, R_, O, T = ids.shape
+    U = batch["dec_input_ids"].shape[-1]
+    n = B * R_ * O
+    flat = lambda k, L: batch[k].reshape(n, L)
+    dial = torch.arange(B).repeat_interleave(R_ * O)
+    out = []
+    rows = max(1, rounds_per_call) * O
+    for s in range(0, n, rows):
+        e = slice(s, min(s + rows, n))
+        d = dial[e]
+        out.append(model.score_candidates(batch["enc_image_feat"][d].to(device), batch["enc_image_loc"][d].to(device),
+                                          batch["enc_image_mask"][d].to(device), flat("enc_input_ids", T)[e].to(device),
+                                          flat("enc_segments", T)[e].to(device), flat("enc_att_mask", T)[e].to(device),
+                                          flat("dec_input_ids", U)[e].to(device), flat("dec_att_mask", U)[e].to(device), 1))
     return torch.cat(out).view(B, R_, O)
 
 

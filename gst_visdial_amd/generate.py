@@ -43,15 +43,21 @@ def append_to_context(ctx_ids, ctx_len, new_ids, sep_id, segments=None, segment_
 
 
 @torch.no_grad()
-def answer_perplexity(model, enc_kwargs, ans_ids):
-    """generate.py:176-201.  `ans_ids` is mutated like the reference mutates it ([SEP] -> [PAD]); returns (ppl, ans_len)."""
-    params = model.params
-    mode = params["mode"]
-    params["mode"] = "train"
-    try:
-        loss, _ = model(dec_input_ids=ans_ids, dec_attention_mask=(ans_ids != 0).float(), loss_reduction=False, **enc_kwargs)
-    finally:
-        params["mode"] = mode
+def answer_perplexity(model, enc_kwargs, ans_ids, reuse_decode_state=False):
+    """generate.py:176-201.  `ans_ids` is mutated like the reference mutates it ([SEP] -> [PAD]); returns (ppl, ans_len).
+    reuse_decode_state=True: `ans_ids` was just sampled by `model` from exactly `enc_kwargs` (nothing ran on the model in
+    between) -- the teacher-forced pass then reuses that call's encoder states and cross-attention K/V
+    (Engine.rescore_sampled) instead of running the encoder a second time, which is what the reference does."""
+    if reuse_decode_state:
+        loss, _ = model.engine.rescore_sampled(ans_ids, (ans_ids != 0).float(), loss_reduction=False)
+    else:
+        params = model.params
+        mode = params["mode"]
+        params["mode"] = "train"
+        try:
+            loss, _ = model(dec_input_ids=ans_ids, dec_attention_mask=(ans_ids != 0).float(), loss_reduction=False, **enc_kwargs)
+        finally:
+            params["mode"] = mode
     ans_len = (ans_ids != 0).sum(-1)
     loss = loss.reshape(ans_ids.shape[0], ans_ids.shape[1]).sum(-1) / ans_len
     return torch.exp(loss), ans_len
@@ -73,7 +79,7 @@ def dialog_round(q_model, a_model, state, sep_id=102, q_kwargs=None, a_kwargs=No
     ques = q_model(dec_input_ids=state["dec_input_ids"], dec_attention_mask=state["dec_attention_mask"], **q_kwargs, **enc())
     _, bad_q = append_to_context(state["enc_input_ids"], state["enc_input_len"], ques, sep_id)
     ans = a_model(dec_input_ids=state["dec_input_ids"], dec_attention_mask=state["dec_attention_mask"], **a_kwargs, **enc())
-    ppl, _ = answer_perplexity(a_model, enc(), ans)
+    ppl, _ = answer_perplexity(a_model, enc(), ans, reuse_decode_state=True)
     _, bad_a = append_to_context(state["enc_input_ids"], state["enc_input_len"], ans, sep_id,
                                  segments=state["enc_segments"], segment_value=1)
     return ques, ans, ppl, torch.cat((bad_q, bad_a))

@@ -5,7 +5,24 @@ about as much as the GPU work itself.  `GraphedStep` runs the step function eage
 device table, LDS attribute and arena chunk exists), captures one invocation into a hipGraph and replays it.
 Requirements the engine meets: static addresses (bump arena, flat parameter buffers), no host synchronisation in
 the step, device-resident mutable state (dropout offset, AdamW step counter), inputs refreshed IN PLACE by the
-caller (`tensor.copy_(new)`), learning-rate tables uploaded outside the graph (`FusedAdamW.upload_lr`)."""
+caller (`tensor.copy_(new)`), learning-rate tables uploaded outside the graph (`FusedAdamW.upload_lr`).
+
+Every stream capture of this package goes through `capture()` below, which makes the two things that may not happen
+while a capture is open impossible instead of unlikely:
+
+  * a cyclic-GC pass.  torch >= 2.9 no longer calls gc.collect() in torch.cuda.graph.__enter__; an automatic pass in the
+    middle of a capture that finds a dead object graph owning CUDAGraphs / a private memory pool (e.g. the engine of an
+    earlier model with a captured decode session) runs ~CUDAGraph -> pool release -> hipFree under an open "global" mode
+    capture: the call is refused, the destructor throws, std::terminate -> SIGABRT (round 1's GPUTEST abort;
+    tools/repro_gc_capture.py reproduces it on demand).  Here: collect BEFORE the capture, collector off during it.
+  * c10d's watchdog thread polling the event of a not-yet-retired eager collective (see quiesce_before_capture).
+"""
+import contextlib
+import gc
+import os
+import pickle
+import time
+
 import torch
 
 
@@ -13,15 +30,47 @@ def dist_alive():
     return torch.distributed.is_available() and torch.distributed.is_initialized()
 
 
-def quiesce_before_capture():
+def enable_watchdog_introspection():
+    """Call BEFORE init_process_group: turns c10d's flight recorder on (a small ring), which is the only public window on
+    what the watchdog thread still has on its list; `quiesce_before_capture` then waits on facts instead of on a timer."""
+    os.environ.setdefault("TORCH_NCCL_TRACE_BUFFER_SIZE", "512")
+
+
+def _active_collectives():
+    """Number of collectives the watchdog has not retired yet, or None when the flight recorder is off / unavailable."""
+    try:
+        from torch._C._distributed_c10d import _dump_nccl_trace
+        if int(os.environ.get("TORCH_NCCL_TRACE_BUFFER_SIZE", os.environ.get("TORCH_FR_BUFFER_SIZE", "0"))) <= 0:
+            return None
+        tr = pickle.loads(_dump_nccl_trace(includeCollectives=True, includeStackTraces=False, onlyActive=True))
+        ent = tr.get("entries") if isinstance(tr, dict) else None
+        return None if ent is None else len(ent)
+    except Exception:
+        return None
+
+
+def quiesce_before_capture(timeout=20.0):
     """Call right before a stream capture.  c10d's watchdog thread polls the events of eager collectives until it has seen
-    them complete (about every 100 ms).  If a capture starts while such a Work is still on its list, the poll can hit an
+    them complete (a pass every ~100 ms).  If a capture starts while such a Work is still on its list, the poll can hit an
     event of the capturing stream: the capture is invalidated (hipErrorStreamCaptureInvalidated) and the watchdog's own
-    exception aborts the process -- observed in ~1 of 6 runs, 0 of 24 with this wait."""
+    exception aborts the process (round 1: 1 run in 6).  Deterministic form: (1) device idle -> every eager collective has
+    completed; (2) wait until the flight recorder reports no un-retired collective, i.e. the watchdog has popped them all.
+    Without the recorder (TORCH_NCCL_TRACE_BUFFER_SIZE unset before init_process_group) fall back to five watchdog periods."""
     torch.cuda.synchronize()
-    if dist_alive():
-        import time
-        time.sleep(2.0)
+    if not dist_alive():
+        return "no-process-group"
+    t0 = time.time()
+    n = _active_collectives()
+    if n is None:
+        time.sleep(0.5)
+        return "timer"
+    while n > 0:
+        if time.time() - t0 > timeout:
+            raise RuntimeError("c10d watchdog still holds %d un-retired collectives after %.0f s; refusing to capture" % (n, timeout))
+        time.sleep(0.01)
+        n = _active_collectives()
+    time.sleep(0.12)          # one more watchdog period: the pass that retired the last Work has left the event API
+    return "drained"
 
 
 def capture_error_mode():
@@ -29,14 +78,49 @@ def capture_error_mode():
     return "thread_local" if dist_alive() else "global"
 
 
+_GC_DEPTH = [0]
+
+
+@contextlib.contextmanager
+def gc_quiet():
+    """Collect now, then keep the cyclic collector off for the duration (re-entrant: an inner use is a no-op, which is how
+    a decode session pays for ONE collection although it captures ~20 graphs).  The collection also runs when the caller has
+    the collector switched off: the dead cycles must be gone before the capture opens, whoever would have collected them."""
+    outer = _GC_DEPTH[0] == 0
+    _GC_DEPTH[0] += 1
+    was_enabled = gc.isenabled()
+    if outer:
+        gc.collect()
+        gc.disable()
+    try:
+        yield
+    finally:
+        _GC_DEPTH[0] -= 1
+        if outer and was_enabled:
+            gc.enable()
+
+
+@contextlib.contextmanager
+def capture(graph, pool=None, quiesce=True):
+    """The only way this package opens a stream capture (see the module docstring).  `quiesce=False`: the caller has
+    just captured another graph and issued no collective since (the per-position graphs of a decode session)."""
+    if quiesce:
+        quiesce_before_capture()
+    with gc_quiet():
+        kw = dict(capture_error_mode=capture_error_mode())
+        if pool is not None:
+            kw["pool"] = pool
+        with torch.cuda.graph(graph, **kw):
+            yield graph
+
+
 class GraphedStep(object):
     def __init__(self, step_fn, warmup=2):
         self.step_fn = step_fn
         for _ in range(warmup):
             self.out = step_fn()
-        quiesce_before_capture()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode=capture_error_mode()):
+        with capture(self.graph):
             self.out = step_fn()
 
     def __call__(self):

@@ -22,9 +22,33 @@ def warmup_linear_nonzero(step, warmup_steps, t_total, base_lr, min_lr=1e-5):
     return base_lr * f if base_lr * f > min_lr else min_lr
 
 
+def reference_param_index(model):
+    """[(name, parameter | None)] in the order the reference builds its per-tensor param groups (train_gen.py:209-245):
+    `dialog_encoder.named_parameters()` then `dialog_decoder.named_parameters()`, both taken BEFORE the embedding aliasing
+    of train_gen.py:293.  Two consequences of that order, both reproduced here so that group/state indices line up with
+    the reference's `optimizer.state_dict()`:
+      * the decoder's own embedding tensors are in the list; after the aliasing they are orphans that never see a
+        gradient (-> None here: no state), EXCEPT its word embedding, which the LM head keeps as its weight
+        (visual_dialog_decoder.py:124,329-335): that slot is `decoder.lm_head.decoder.weight`;
+      * `lm_head.decoder.weight` itself is not listed a second time (named_parameters de-duplicates the tied tensor)."""
+    dec_mod = model.decoder.decoder
+    if dec_mod.bert.embeddings is not model.encoder.bert_pretrained.bert.embeddings:
+        raise NotImplementedError("reference optimizer state is defined for the train_gen.py set-up: share the embeddings "
+                                  "first (decoder.decoder.bert.embeddings = encoder.bert_pretrained.bert.embeddings)")
+    out = [("encoder." + k, p) for k, p in model.encoder.named_parameters()]
+    lm_w = dec_mod.lm_head.decoder.weight
+    for k, p in model.decoder.named_parameters():
+        if p is lm_w:
+            continue
+        if k.startswith("decoder.bert.embeddings."):
+            p = lm_w if k == "decoder.bert.embeddings.word_embeddings.weight" else None
+        out.append(("decoder." + k, p))
+    return out
+
+
 class FusedAdamW(object):
     def __init__(self, model, lr=2e-5, image_lr=None, language_weights=None, weight_decay=0.01, betas=(0.9, 0.999),
-                 eps=1e-6, warmup_steps=0, t_total=0, min_lr=1e-5):
+                 eps=1e-6, warmup_steps=0, t_total=0, min_lr=1e-5, train_vlfusion=False):
         self.model, self.engine = model, model.engine
         self.betas, self.eps = betas, eps
         self.lr = lr
@@ -32,11 +56,16 @@ class FusedAdamW(object):
         self.language_weights = set(language_weights) if language_weights is not None else None
         self.weight_decay = weight_decay
         self.warmup_steps, self.t_total, self.min_lr = warmup_steps, t_total, min_lr
+        # Reference quirk, preserved by default: train_gen.py:209-245 builds its param groups from dialog_encoder and
+        # dialog_decoder only -- EncoderDecoderModel.vlfusion (visual_dialog_model.py:22) is in neither, so the reference never
+        # updates fc_v / fc_l (golden: tests/golden/tiny_trainer.npz keeps them bit-identical over 6 iterations).
+        self.train_vlfusion = train_vlfusion
         self.sched_step = 0          # scheduler.step() count (train_gen.py:329 steps it every iteration)
         self.opt_step = 0            # optimizer.step() count
         self.grad_scale = 1.0        # e.g. 1/world_size after a summing all-reduce
         self._built = False
         self._applied_in_backward = False
+        self._pending = None         # a state dict loaded before the flat buffers existed (train_gen.py:254-276 loads first)
 
     def _names(self):
         """Parameter names relative to the encoder / decoder module, as train_gen.py:211,229 sees them."""
@@ -61,7 +90,8 @@ class FusedAdamW(object):
             n = names[id(p)]
             lr = self.lr if (self.language_weights is None or n in self.language_weights) else self.image_lr
             wd = 0.0 if any(nd in n for nd in NO_DECAY) else self.weight_decay
-            ends.append(off + p.numel()); base.append((lr, wd, 1.0))
+            frozen = n.startswith("vlfusion.") and not self.train_vlfusion
+            ends.append(off + p.numel()); base.append((0.0, 0.0, 0.0) if frozen else (lr, wd, 1.0))
             prev = off + p.numel()
         if prev < flat.n_live:
             ends.append(flat.n_live); base.append((0.0, 0.0, 0.0))
@@ -69,11 +99,26 @@ class FusedAdamW(object):
         self.base = base
         self.hp_host = torch.empty(len(base) * 2, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.empty(len(base) * 2)
         self.hp = torch.empty(len(base) * 2, dtype=torch.float32, device=dev)
+        old = (self.m, self.v) if self._built and self.m.numel() == flat.P.numel() else None
         self.m = torch.zeros_like(flat.P)
         self.v = torch.zeros_like(flat.P)
-        self.step_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        if old is not None:                      # the flat buffers were re-materialised (model.to(), aliasing): keep the moments
+            self.m.copy_(old[0]); self.v.copy_(old[1])
+        # bias correction reads this counter on the device (loss.hip adamw_kernel): it must follow opt_step across resumes
+        self.step_dev = torch.full((1,), float(self.opt_step), dtype=torch.float32, device=dev)
         self._built, self._flat_id = True, id(flat.P)
         self._last_lr_key = None
+        if self._pending is not None:
+            sd, self._pending = self._pending, None
+            self._apply_state(sd)
+
+    def _ensure_built(self):
+        flat = self.engine.flat
+        if flat is None or flat.P is None:
+            return False
+        if not self._built or self._flat_id != id(flat.P):
+            self._build()
+        return True
 
     def current_lrs(self):
         if self.t_total > 0:
@@ -95,11 +140,8 @@ class FusedAdamW(object):
 
     def begin_step(self):
         """Advance the step counter (device resident: correct under hipGraph replay) and make sure the lr table is current."""
-        flat = self.engine.flat
-        if flat is None or flat.P is None:
+        if not self._ensure_built():
             raise RuntimeError("FusedAdamW before the first forward")
-        if not self._built or self._flat_id != id(flat.P):
-            self._build()
         self._upload_hp()                 # host->device only when the learning rate changed (never inside a captured graph)
         self.opt_step += 1
         self.step_dev.add_(1.0)
@@ -139,10 +181,78 @@ class FusedAdamW(object):
             p.grad = None
 
     def state_dict(self):
+        if self._pending is not None and "per_tensor" not in self._pending:
+            return dict(self._pending)
         return dict(m=self.m, v=self.v, opt_step=self.opt_step, sched_step=self.sched_step) if self._built else {}
 
     def load_state_dict(self, sd):
-        if not self._built:
-            self._build()
+        """Usable BEFORE the first forward, as train_gen.py:254-276 does it (checkpoint first, then training): the state is
+        kept and applied as soon as the flat buffers exist.  Restores the device step counter too -- AdamW's bias correction
+        sqrt(1-b2^t)/(1-b1^t) must continue at t = opt_step, not restart at 1 on warm moments."""
+        self.opt_step, self.sched_step = int(sd["opt_step"]), int(sd["sched_step"])
+        self._pending = sd
+        self._ensure_built()         # applies it now when the engine is ready; otherwise begin_step() will
+        if self._built and self._pending is not None:
+            sd, self._pending = self._pending, None
+            self._apply_state(sd)
+
+    # ---- the reference's on-disk optimizer layout (train_gen.py:349 saves optimizer.state_dict(), :254-276 loads it) ----
+    def export_reference_state(self):
+        """-> {'state': {index: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [...]}: what the reference's
+        pytorch_transformers AdamW (a torch.optim.Optimizer) would hold after the same steps -- one group per tensor in
+        `reference_param_index` order, state only for tensors that have received gradients."""
+        if not self._ensure_built():
+            raise RuntimeError("FusedAdamW before the first forward")
+        flat = self.engine.flat
+        off_of = {id(p): off for p, off in flat.items}
+        names = self._names()
+        lr_t, lr_i = self.current_lrs()
+        state, groups = {}, []
+        for i, (name, p) in enumerate(reference_param_index(self.model)):
+            key = names.get(id(p), name) if p is not None else name.split(".", 1)[1]
+            base = self.lr if (self.language_weights is None or key in self.language_weights) else self.image_lr
+            wd = 0.0 if any(nd in key for nd in NO_DECAY) else self.weight_decay
+            groups.append(dict(lr=(lr_t if base == self.lr else lr_i), initial_lr=base, betas=tuple(self.betas), eps=self.eps,
+                               weight_decay=wd, correct_bias=True, params=[i]))
+            if p is not None and id(p) in off_of and self.opt_step > 0:
+                o, n = off_of[id(p)], p.numel()
+                state[i] = dict(step=self.opt_step, exp_avg=self.m[o:o + n].view(p.shape).clone(),
+                                exp_avg_sq=self.v[o:o + n].view(p.shape).clone())
+        return dict(state=state, param_groups=groups)
+
+    def import_reference_state(self, osd):
+        """Load a reference-format optimizer state (see export_reference_state); usable before the first forward."""
+        idx = reference_param_index(self.model)
+        st = osd["state"]
+        step = max([int(v["step"]) for v in st.values()] or [0])
+        pend = []
+        for i, (name, p) in enumerate(idx):
+            e = st.get(i, st.get(str(i)))
+            if e is None or p is None:
+                continue
+            if tuple(e["exp_avg"].shape) != tuple(p.shape):
+                raise RuntimeError("optimizer state %d (%s): shape %s vs parameter %s" % (i, name, tuple(e["exp_avg"].shape), tuple(p.shape)))
+            pend.append((p, e["exp_avg"], e["exp_avg_sq"]))
+        self.opt_step = step
+        self._pending = dict(per_tensor=pend, opt_step=step, sched_step=self.sched_step)
+        if self._ensure_built() and self._pending is not None:
+            sd, self._pending = self._pending, None
+            self._apply_state(sd)
+
+    def _apply_state(self, sd):
+        if "per_tensor" in sd:
+            off_of = {id(p): off for p, off in self.engine.flat.items}
+            self.m.zero_(); self.v.zero_()
+            for p, ea, eas in sd["per_tensor"]:
+                o, n = off_of[id(p)], p.numel()
+                self.m[o:o + n].copy_(ea.reshape(-1)); self.v[o:o + n].copy_(eas.reshape(-1))
+            self.opt_step = int(sd["opt_step"])
+            self.step_dev.fill_(float(self.opt_step))
+            self._last_lr_key = None
+            return
+        if sd["m"].numel() != self.m.numel():
+            raise RuntimeError("optimizer state holds %d elements, the model's flat buffer %d" % (sd["m"].numel(), self.m.numel()))
         self.m.copy_(sd["m"]); self.v.copy_(sd["v"])
         self.opt_step, self.sched_step = int(sd["opt_step"]), int(sd["sched_step"])
+        self.step_dev.fill_(float(self.opt_step))
+        self._last_lr_key = None

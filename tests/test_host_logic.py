@@ -5,6 +5,7 @@ import json
 import os
 import tempfile
 
+import pytest
 import torch
 
 from conftest import GOLDEN, load_npz
@@ -294,3 +295,46 @@ def test_vectorised_ngram_blocking_equals_the_reference_loops():
         a = batch_ngram_blocking(logits.clone(), hist, dec, ngram_size=n)
         b = _ngram_blocking_loop(logits.clone(), hist, dec, ngram_size=n)
         assert torch.equal(a, b), (trial, n, cur, T)
+
+
+def test_reference_optimizer_param_order_matches_the_reference_run():
+    """optim.reference_param_index == the order (and the set of tensors that ever get optimizer state) of the reference's own
+    per-tensor param groups (tests/golden/tiny_trainer.json, written by oracle/make_golden_r2.py from the real modules)."""
+    from gst_visdial_amd.optim import reference_param_index
+    from gst_visdial_amd.engine import FlatParams
+    meta = json.load(open(os.path.join(GOLDEN, "tiny_trainer.json")))
+    model, enc, dec = _tiny_model()
+    with pytest.raises(NotImplementedError):
+        reference_param_index(model)                                             # defined for the aliased (train_gen.py) set-up
+    dec.decoder.bert.embeddings = enc.bert_pretrained.bert.embeddings            # train_gen.py:293
+    idx = reference_param_index(model)
+    assert [n for n, _ in idx] == meta["param_names"]
+    assert [list(p.shape) if p is not None else meta["shapes"][i] for i, (_, p) in enumerate(idx)] == meta["shapes"]
+    fp = FlatParams(model, "fp32")
+    live = set(id(p) for p in fp.live)
+    assert [i for i, (_, p) in enumerate(idx) if p is not None and id(p) in live] == meta["stateful_indices"]
+    assert not any(n.startswith("vlfusion") for n, _ in idx)                     # never in the reference's optimizer
+
+
+def test_inverse_cdf_draw():
+    from gst_visdial_amd.decoding import draw_from_uniform
+    p = torch.tensor([[0.0, 0.2, 0.0, 0.8], [0.5, 0.5, 0.0, 0.0], [0.0, 0.0, 0.0, 1.0]])
+    assert draw_from_uniform(p, torch.tensor([0.1, 0.7, 0.999])).view(-1).tolist() == [1, 1, 3]
+    assert draw_from_uniform(p, torch.tensor([0.3, 0.2, 1e-6])).view(-1).tolist() == [3, 0, 3]
+    g = torch.Generator().manual_seed(0)
+    pr = torch.softmax(torch.randn(1, 50, generator=g), -1).expand(20000, 50)
+    idx = draw_from_uniform(pr, torch.rand(20000, generator=g)).view(-1)
+    freq = torch.bincount(idx, minlength=50).float() / 20000
+    assert (freq - pr[0]).abs().max() < 0.01                                     # it IS a draw from prob
+
+
+def test_capture_guard_collects_before_and_disables_gc_during():
+    import gc
+    from gst_visdial_amd import graph
+    seen = []
+    with graph.gc_quiet():
+        seen.append(gc.isenabled())
+        with graph.gc_quiet():
+            seen.append(gc.isenabled())
+        seen.append(gc.isenabled())
+    assert seen == [False, False, False] and gc.isenabled()

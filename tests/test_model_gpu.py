@@ -170,6 +170,7 @@ def test_sampling_decode_matches_reference_argmax_path(monkeypatch):
     assert torch.equal(seq.cpu(), d["sequence"])
 
 
+@pytest.mark.isolated
 def test_graph_captured_decode_equals_eager_decode(monkeypatch):
     """generate.py calls the decode branch batch after batch with the same shapes: from the second call on the device
     work is replayed from hipGraphs (encoder side + one graph per decoder position).  Same token ids as the eager path,
@@ -221,6 +222,7 @@ def test_smoke_entry_point():
     ge.smoke()
 
 
+@pytest.mark.isolated
 def test_graph_replay_reproduces_eager_training_steps():
     """hipGraph replay of the whole step (forward + two-stream backward + fused AdamW) == the same steps issued eagerly."""
     from gst_visdial_amd.optim import FusedAdamW
@@ -536,7 +538,7 @@ def test_training_trajectory_matches_oracle_autograd_plus_reference_adamw():
         lr = warmup_linear_nonzero(step - 1, warm, total, base_lr, 1e-5)       # scheduler.step() follows optimizer.step()
         for k in keys:
             gk = grads[k]
-            if gk is None:
+            if gk is None or k.startswith("vlfusion."):      # VLFusion is in none of the reference's param groups (train_gen.py:209-245)
                 continue
             m[k].mul_(b1).add_(gk, alpha=1 - b1)
             v[k].mul_(b2).addcmul_(gk, gk, value=1 - b2)
@@ -586,6 +588,7 @@ def test_bf16_training_tracks_fp32_training():
         assert abs(x - y) <= 0.03 * abs(x) + 0.02, (a, b)
 
 
+@pytest.mark.isolated
 def test_pipeline_with_rccl_collectives_single_rank_group():
     """The N>1 code path on one GPU: a 1-rank RCCL process group, BackwardPipeline with force_collective (the all-reduce of
     every slice really goes through RCCL), fp32 and bf16-compressed gradients, eager and hipGraph-captured.  With one
@@ -642,6 +645,7 @@ def test_pipeline_with_rccl_collectives_single_rank_group():
             dist.destroy_process_group()
 
 
+@pytest.mark.isolated
 def test_dialog_round_perplexity_and_context_update():
     """gst_visdial_amd.generate (generate.py:122-228): sample a question, append it, sample an answer, score it with the
     answerer ("ppl trick"), append it with segment 1.  The perplexity equals the oracle's on the same context and answer;

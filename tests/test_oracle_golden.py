@@ -131,3 +131,117 @@ def test_schedule_order_full_config():
     assert order[7:10] == [("v", 0), ("t", 6), ("c", 1)]
     assert order[-2:] == [("v", 5), ("t", 11)]
     assert len(order) == 24
+
+
+# ---- round-2 fixtures (oracle/make_golden_r2.py: the reference run on an eval set / under real sampling / in train_gen's loop)
+def _expanded_eval_rows(ev, tag=""):
+    """evaluate_gen.py:45-92: [B, rounds, options, L] -> one row per (dialog, round, option), image tensors expanded."""
+    ids = ev[tag + "in::enc_input_ids"]
+    B, NR, G, T = ids.shape
+    n = B * NR * G
+    dial = torch.arange(B).repeat_interleave(NR * G)
+    b = dict(enc_input_ids=ids.reshape(n, T), enc_segments=ev[tag + "in::enc_segments"].reshape(n, T),
+             enc_attention_mask=ev[tag + "in::enc_att_mask"].reshape(n, T),
+             enc_image_features=ev[tag + "in::enc_image_feat"][dial], enc_image_spatials=ev[tag + "in::enc_image_loc"][dial],
+             enc_image_mask=ev[tag + "in::enc_image_mask"][dial],
+             dec_input_ids=ev[tag + "in::dec_input_ids"].reshape(n, -1).clone(),
+             dec_attention_mask=ev[tag + "in::dec_att_mask"].reshape(n, -1), dec_labels=None)
+    return b, (B, NR, G)
+
+
+def test_eval_set_scores_ranks_and_metrics(tiny_cfg, tiny_state):
+    from conftest import load_npz
+    enc, dec = tiny_cfg
+    ev = load_npz("tiny_evalset.npz")
+    for tag in ("", "attacked::"):
+        b, (B, NR, G) = _expanded_eval_rows(ev, tag)
+        unmutated = b["dec_input_ids"].clone()
+        out = O.model_forward(tiny_state, enc, dec, b)
+        scores = O.answer_scores(out["logits"], unmutated).view(B, NR, G)
+        close(scores, ev[tag + "scores"], 1e-4)
+        assert ev[tag + "min_score_gap"].item() > 1e-2
+        assert torch.equal(O.scores_to_ranks(scores), ev[tag + "ranks"])                    # index work: bit-exact
+        m = O.sparse_metrics(O.gt_ranks(scores, ev[tag + "in::gt_option_inds"]))
+        got = torch.tensor([m[k] for k in ("r@1", "r@5", "r@10", "mean", "mrr")], dtype=torch.float64)
+        close(got, ev[tag + "sparse"], 1e-6)
+        rid = ev[tag + "in::round_id"].squeeze(1)
+        nd = O.ndcg_batch(scores[torch.arange(B), rid - 1, :], ev[tag + "in::gt_relevance"]).mean()
+        close(nd.double().reshape(1), ev[tag + "ndcg"].double(), 1e-6)
+    assert not torch.equal(ev["scores"], ev["attacked::scores"])
+
+
+def test_sampling_decode_under_recorded_uniforms(tiny_cfg, tiny_state, tiny_train):
+    """Real sampling (temperature 1.3, top-k 40): the reference drew by inverse CDF from the recorded uniforms."""
+    from conftest import load_npz
+    enc, dec = tiny_cfg
+    sm = load_npz("tiny_sampled.npz")
+    assert sm["margin"].item() > 5e-4                     # every draw sits >= 5e-4 inside its CDF cell: 1e-4 logit noise cannot flip it
+    b = batch_from_golden(tiny_train)
+    b["dec_input_ids"] = torch.full((b["enc_input_ids"].shape[0], 1), 101, dtype=torch.long)
+    u, t = sm["uniforms"], [0]
+
+    def draw(prob):
+        c = torch.cumsum(prob.float(), dim=-1)
+        x = u[t[0]].reshape(-1, 1) * c[:, -1:]
+        t[0] += 1
+        return (c < x).sum(-1, keepdim=True).clamp(max=prob.shape[-1] - 1)
+
+    seq, _ = O.sampling_decode(tiny_state, enc, dec, b, temperature=float(sm["temperature"]), top_k=int(sm["top_k"]), top_p=0.0,
+                               ngram_blocking_size=2, draw=draw)
+    assert torch.equal(seq, sm["sequence"])
+    assert (seq != 0).sum() > 30 and len(set(seq.reshape(-1).tolist())) > 20             # a real, varied sample
+
+
+def test_train_loop_with_restated_adamw_follows_the_reference_run(tiny_cfg, tiny_state, tiny_train):
+    """train_gen.py:300-329 (iteration-0 quirk, per-tensor groups, two learning rates, warm-up schedule) restated on the
+    oracle's autograd + oracle/ref_adamw.py reproduces the losses and the parameters of the reference model's own run."""
+    from conftest import load_npz
+    from oracle import ref_adamw
+    enc, dec = tiny_cfg
+    tr = load_npz("tiny_trainer.npz")
+    meta = json.load(open(os.path.join(GOLDEN, "tiny_trainer.json")))
+    sd = {k: v.clone() for k, v in tiny_state.items()}
+    keys = [k for k in O.live_param_keys(sd) if k in sd]
+    params = {k: torch.nn.Parameter(sd[k].clone()) for k in keys}
+    lang = set(meta["language_weights"])
+
+    def hp(k):           # the group the reference put this tensor in (names relative to the encoder / decoder module)
+        rel = k.split(".", 1)[1]
+        if k == "decoder.decoder.lm_head.decoder.weight":
+            rel = "decoder.bert.embeddings.word_embeddings.weight"
+        lr = meta["lr"] if rel in lang else meta["image_lr"]
+        return lr, (0.0 if any(nd in rel for nd in ref_adamw.NO_DECAY) else 0.01)
+
+    # the reference hands ONLY the encoder's and the decoder's tensors to its optimizer (train_gen.py:209-245): the VLFusion
+    # projections live on EncoderDecoderModel itself and are never updated
+    assert not any("vlfusion" in n for n in meta["param_names"])
+    groups = [dict(params=[params[k]], lr=hp(k)[0], weight_decay=hp(k)[1]) for k in keys if not k.startswith("vlfusion.")]
+    opt = ref_adamw.AdamW(groups, lr=meta["lr"])
+    base = [g["lr"] for g in groups]
+    cpu_b = batch_from_golden(tiny_train)
+    losses = []
+    for it in range(6):
+        cur = dict(sd)
+        cur.update({k: p.data for k, p in params.items()})
+        out, grads, _ = O.grads(cur, enc, dec, cpu_b, keys, wrt_feats=False)
+        for k in keys:
+            if grads[k] is not None:
+                params[k].grad = grads[k] if params[k].grad is None else params[k].grad + grads[k]
+        for g, b0 in zip(opt.param_groups, base):
+            g["lr"] = O.warmup_linear_nonzero_lr(it, b0, meta["warmup_steps"], meta["t_total"])
+        if it > 0:
+            opt.step()
+            opt.zero_grad()
+        losses.append(out["loss"].item())
+        if it == 3:
+            osd = opt.state_dict()
+            i198 = meta["param_names"].index("decoder.decoder.bert.embeddings.word_embeddings.weight")
+            j = [k for k in keys if not k.startswith("vlfusion.")].index("decoder.decoder.lm_head.decoder.weight")
+            ref_m = tr["opt3::%d::exp_avg" % i198]
+            close(osd["state"][j]["exp_avg"] / ref_m.abs().max(), ref_m / ref_m.abs().max(), 2e-3)
+            assert int(tr["opt3::%d::step" % i198]) == osd["state"][j]["step"] == 3
+    close(torch.tensor(losses, dtype=torch.float64), tr["losses"].double(), 2e-5)
+    assert losses[0] == losses[1]                                   # nothing moved at iteration 0
+    worst = max((params[k].data - tr["state5::" + k]).abs().max().item() / max(tr["state5::" + k].abs().max().item(), 1e-6) for k in keys)
+    assert worst < 2e-4, worst
+    assert torch.equal(tr["state5::vlfusion.fc_v.weight"], tiny_state["vlfusion.fc_v.weight"])       # never trained by the reference
