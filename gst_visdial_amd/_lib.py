@@ -71,6 +71,7 @@ SIGNATURES = {
     "gstvd_gemm_splitk_ws_bytes": (_i64, [_i64, _i64, _i32]),
     "gstvd_gemm_splitk": (_i32, [_vp, _i32, _vp, _i64, _vp]),
     "gstvd_gemm_group_tile": (_i32, []),
+    "gstvd_debug_gemm_clock": (_i32, [_vp, _i32]),
     "gstvd_gemm_grouped": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp]),
     "gstvd_ln_fwd": (_i32, [C.POINTER(LnDesc), _vp]),
     "gstvd_ln_bwd_blocks": (_i64, [_i64]),

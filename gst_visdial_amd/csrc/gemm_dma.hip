@@ -171,7 +171,8 @@ DEVFN void dma_tile(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char* s
 
   const int g = lane >> 4, li = lane & 15;
   const DropKey dk = make_drop((p.epi & GSTVD_EPI_DROPOUT) ? p.p : 0.f, p.site, p.rng);
-  if constexpr (sizeof(OT) == 2) {
+  constexpr int EPI_LPR = NI <= 1 ? 2 : (NI <= 2 ? 4 : 8);           // lanes per row of the row-wise epilogue
+  if constexpr (sizeof(OT) == 2 && (MI < 4 ? MI : 4) * 16 >= 64 / EPI_LPR) {      // (a 16x16 wave tile has too few rows for it)
     if (epilogue_rows_ok(p)) {
       constexpr int HB = MI < 4 ? MI : 4;
       static_assert(WM * WN * epi_wave_bytes<NI, HB>() <= NS * STAGE, "epilogue parking must fit in the ring");
@@ -236,6 +237,9 @@ static int dma_layout(const GemmP& p, int64_t batch, hipStream_t s) {
     return dma_launch<OT, 128, 128, 2, 4, AKM, BKM, 5>(p, batch, s);
   }
   if (variant == 3) return dma_launch<OT, 64, 64, 2, 2, AKM, BKM, 4>(p, batch, s);
+  // (32x32 / 32x64 tiles for the skinny M = 400 / 592 problems were measured in round 2: no faster -- 400x768x768 9.8-11.0 us
+  // against 10.2 us, 592x1024x1024 16.5 us against 13.1 us -- the ring of a workgroup is latency bound, 7 stages x stage
+  // bytes in flight per ~2 us round trip, so halving the tile halves the bytes in flight along with the bytes needed.)
   return dma_launch<OT, 64, 64, 2, 2, AKM, BKM, 8>(p, batch, s);
 }
 

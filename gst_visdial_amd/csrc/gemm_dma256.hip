@@ -15,6 +15,10 @@
 static __device__ __attribute__((aligned(256))) char g_zero_page256[256];
 static constexpr int g_strip_w = 8;      // column-strip width of the tile order (measured 2 / 4 / 8: 31.3 / 30.7 / 30.5 us at 4096x3072x768)
 constexpr int NS256 = 5;    // ring depth: 5 x 32 KB = the whole 160 KB LDS of a CU
+// Diagnostic build only (GSTVD_GEMM_ST=3, never the default): shader-clock and 100 MHz wall-clock stamps around the K loop of
+// the first 512 workgroups, written to a buffer of their own -- in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz
+// (MI355X_MICROARCH.md, DVFS item 6).  gstvd_debug_gemm_clock() copies them out.
+static __device__ unsigned long long g_clk256[512 * 4];
 
 
 DEVFN int rm32_off(int row, int slot) { return row * 64 + ((slot ^ (((row >> 3) & 1) << 1)) << 4); }
@@ -79,7 +83,14 @@ struct Dma32 {
 
 // NIU = 16-column accumulator tiles per wave actually used (4: the full 256-wide tile; 3: a 192-wide tile inside the same
 // 256-wide LDS image -- N = 3072 then gives 16 x 16 = 256 tiles, one per CU, instead of 192 tiles on 256 CUs).
-template <typename OT, bool AKM, bool BKM, int PF, int NIU = 4>
+// ST = stagger of the LDS-DMA issue inside a K-step.  All eight waves used to run the same sequence -- wait, barrier, issue
+// their 4 DMA pieces (~100+ cycles of issue each), read fragments, 32 MFMAs -- so both waves of a SIMD sat in the DMA-issue
+// phase together and the matrix pipe idled meanwhile (0.95 us per step against 0.43 us of MFMA work).  ST = 1: waves 0-3
+// (first wave of every SIMD) issue early as before, waves 4-7 issue their A pieces after half of their MFMAs and their B pieces
+// after the rest: one wave of a SIMD feeds the matrix pipe while its partner talks to the memory pipeline.  ST = 2: the late
+// half issues everything after its MFMAs.  The ring accounting is unchanged (a wave still issues LPS pieces per step, the
+// slot being filled was released by this step's barrier).
+template <typename OT, bool AKM, bool BKM, int PF, int NIU = 4, int ST = 0>
 DEVFN void dma_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char* smem) {
   constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NS = NS256, NT = 512;
   constexpr int WTM = BM / WM, WTN = NIU * 16, MI = WTM / 16, NI = NIU, BNU = WN * WTN;   // 8 x NIU accumulator tiles per wave
@@ -115,16 +126,50 @@ DEVFN void dma_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char
     ub.issue(s, p.K, smem + s * STAGE + A_BYTES, wave);
   }
   int slot = 0, fill = NS - 1;
+  unsigned long long clk0 = 0, rt0 = 0;
+  if (ST == 3) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
   for (int64_t t = 0; t < nkt; ++t) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPS) : "memory");
+    if (PF != -7) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPS) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    // PF = -7: like -1 but not even zero-page DMAs are issued inside the loop (pure LDS-read + MFMA + barrier loop)
     // PF = -1 / -2 / -6 are timing-only ablations (wrong results): -1 = no DMA inside the loop, -2 = no LDS reads / MFMA,
     // -6 = no epilogue
-    if (PF == -1) {
+    const bool late = (ST == 1 || ST == 2) && wave >= 4;       // wave-uniform
+    if (ST == 4 && PF != -2) {
+      // fragment reads first, all twelve of them (48 VGPRs): the compiler's own schedule reads two A fragments at a time right
+      // before the eight MFMAs that use them, which leaves the matrix pipe waiting on LDS latency eight times per step
+      // (in-kernel stamps: 1617 cycles per step for 1024 cycles of MFMA work with the DMA switched off).  Then the DMA issue,
+      // under the reads' latency; then 32 MFMAs behind counted lgkmcnt waits.
+      const char* cA = smem + slot * STAGE;
+      const char* cB = cA + A_BYTES;
+      bf16x8 fb[NI], fa[MI];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) fb[j] = frag32<BN, BKM>(cB, wn * WTN + j * 16, lane);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fa[i] = frag32<BM, AKM>(cA, wm * WTM + i * 16, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      if (PF == -1) {
+        ua.issue(1 << 20, p.K, smem + fill * STAGE, wave);
+        ub.issue(1 << 20, p.K, smem + fill * STAGE + A_BYTES, wave);
+      } else {
+        ua.issue(t + NS - 1, p.K, smem + fill * STAGE, wave);
+        ub.issue(t + NS - 1, p.K, smem + fill * STAGE + A_BYTES, wave);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = mfma_bf16_k32(fb[j], fa[i], acc[i][j]);
+      slot = (slot + 1 == NS) ? 0 : slot + 1;
+      fill = (fill + 1 == NS) ? 0 : fill + 1;
+      continue;
+    }
+    if (PF == -7) {
+    } else if (PF == -1) {
       ua.issue(1 << 20, p.K, smem + fill * STAGE, wave);      // zero-page DMAs keep the vmcnt bookkeeping identical
       ub.issue(1 << 20, p.K, smem + fill * STAGE + A_BYTES, wave);
-    } else {
+    } else if (!late) {
       ua.issue(t + NS - 1, p.K, smem + fill * STAGE, wave);
       ub.issue(t + NS - 1, p.K, smem + fill * STAGE + A_BYTES, wave);
     }
@@ -136,15 +181,33 @@ DEVFN void dma_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char
       for (int j = 0; j < NI; ++j) fb[j] = frag32<BN, BKM>(cB, wn * WTN + j * 16, lane);
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
+        if (ST == 1 && i == MI / 2) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (late) ua.issue(t + NS - 1, p.K, smem + fill * STAGE, wave);
+          __builtin_amdgcn_sched_barrier(0);
+        }
         const bf16x8 fa = frag32<BM, AKM>(cA, wm * WTM + i * 16, lane);
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = mfma_bf16_k32(fb[j], fa, acc[i][j]);
+      }
+      if (ST == 1 || ST == 2) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (late) {
+          if (ST == 2) ua.issue(t + NS - 1, p.K, smem + fill * STAGE, wave);
+          ub.issue(t + NS - 1, p.K, smem + fill * STAGE + A_BYTES, wave);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     slot = (slot + 1 == NS) ? 0 : slot + 1;
     fill = (fill + 1 == NS) ? 0 : fill + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (ST == 3 && tid == 0 && wg < 512) {
+    g_clk256[wg * 4 + 0] = __builtin_amdgcn_s_memtime() - clk0;
+    g_clk256[wg * 4 + 1] = __builtin_amdgcn_s_memrealtime() - rt0;
+    g_clk256[wg * 4 + 2] = (unsigned long long)nkt;
+  }
 
   const int g = lane >> 4, li = lane & 15;
   const DropKey dk = make_drop((p.epi & GSTVD_EPI_DROPOUT) ? p.p : 0.f, p.site, p.rng);
@@ -285,14 +348,14 @@ DEVFN int xcd_remap256(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
-template <typename OT, bool AKM, bool BKM, int PF, int NIU = 4>
+template <typename OT, bool AKM, bool BKM, int PF, int NIU = 4, int ST = 0>
 __global__ __launch_bounds__(512) void gemm_dma256_kernel(GemmP p, int ntn, int nwg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (PF == -5) pp_tile256<OT, AKM, BKM>(p, blockIdx.y, xcd_remap256(blockIdx.x, nwg), ntn, nwg, smem);
-  else dma_tile256<OT, AKM, BKM, PF, NIU>(p, blockIdx.y, xcd_remap256(blockIdx.x, nwg), ntn, nwg, smem);
+  else dma_tile256<OT, AKM, BKM, PF, NIU, ST>(p, blockIdx.y, xcd_remap256(blockIdx.x, nwg), ntn, nwg, smem);
 }
 
-template <typename OT, bool AKM, bool BKM, int PF>
+template <typename OT, bool AKM, bool BKM, int PF, int ST = 0>
 __global__ __launch_bounds__(512) void gemm_dma256_grouped_kernel(const gstvd_gemm_t* tab, const int* tile_off, int nprob, int total, int chs) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // XCD x (blocks b with b % 8 == x) walks chunks x, x+8, x+16, ... of 2^chs consecutive tiles: neighbours in the table share
@@ -310,7 +373,7 @@ __global__ __launch_bounds__(512) void gemm_dma256_grouped_kernel(const gstvd_ge
   p.sA = p.sB = p.sC = p.sAdd = p.sAux = 0;
   p.epi = g.epilogue; p.alpha = g.alpha; p.p = g.dropout_p; p.site = g.site; p.rng = g.rng;
   const int ntn = (int)((g.N + 255) / 256), ntm = (int)((g.M + 255) / 256);
-  dma_tile256<OT, AKM, BKM, PF>(p, 0, gid - tile_off[lo], ntn, ntm * ntn, smem);
+  dma_tile256<OT, AKM, BKM, PF, 4, ST>(p, 0, gid - tile_off[lo], ntn, ntm * ntn, smem);
 }
 
 constexpr int LDS256 = NS256 * (256 + 256) * 64;           // the ring is the whole LDS of a CU
@@ -319,17 +382,33 @@ template <typename OT, bool AKM, bool BKM>
 static int launch256(const GemmP& p, int64_t batch, int niu, hipStream_t s) {
   auto k0 = gemm_dma256_kernel<OT, AKM, BKM, 0>;
   auto k3 = gemm_dma256_kernel<OT, AKM, BKM, 0, 3>;
+  auto s10 = gemm_dma256_kernel<OT, AKM, BKM, 0, 4, 1>;
+  auto s13 = gemm_dma256_kernel<OT, AKM, BKM, 0, 3, 1>;
+  auto s20 = gemm_dma256_kernel<OT, AKM, BKM, 0, 4, 2>;
+  auto s23 = gemm_dma256_kernel<OT, AKM, BKM, 0, 3, 2>;
+  auto c0 = gemm_dma256_kernel<OT, AKM, BKM, 0, 4, 3>;
+  auto c1 = gemm_dma256_kernel<OT, AKM, BKM, -1, 4, 3>;
+  auto c2 = gemm_dma256_kernel<OT, AKM, BKM, -2, 4, 3>;
+  auto c7 = gemm_dma256_kernel<OT, AKM, BKM, -7, 4, 3>;
+  auto p0 = gemm_dma256_kernel<OT, AKM, BKM, 0, 4, 4>;
+  auto p3 = gemm_dma256_kernel<OT, AKM, BKM, 0, 3, 4>;
+  auto p1 = gemm_dma256_kernel<OT, AKM, BKM, -1, 4, 4>;
   auto ka = gemm_dma256_kernel<OT, AKM, BKM, -1>;
   auto kb = gemm_dma256_kernel<OT, AKM, BKM, -2>;
   auto ke = gemm_dma256_kernel<OT, AKM, BKM, -5>;
   auto kf = gemm_dma256_kernel<OT, AKM, BKM, -6>;
   static int attr_rc = ensure_lds(k0, LDS256) | ensure_lds(k3, LDS256) | ensure_lds(ka, LDS256) | ensure_lds(kb, LDS256) |
-                       ensure_lds(ke, LDS256) | ensure_lds(kf, LDS256);
+                       ensure_lds(ke, LDS256) | ensure_lds(kf, LDS256) | ensure_lds(s10, LDS256) | ensure_lds(s13, LDS256) |
+                       ensure_lds(s20, LDS256) | ensure_lds(s23, LDS256) |
+                       ensure_lds(c0, LDS256) | ensure_lds(c1, LDS256) | ensure_lds(c2, LDS256) | ensure_lds(c7, LDS256) |
+                       ensure_lds(p0, LDS256) | ensure_lds(p3, LDS256) | ensure_lds(p1, LDS256);
   if (attr_rc) return attr_rc;
   static const int abl = [] { const char* e = getenv("GSTVD_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
+  static const int st = [] { const char* e = getenv("GSTVD_GEMM_ST"); return e ? atoi(e) : 0; }();
   const int bnu = (niu == 3 && abl == 0) ? 192 : 256;
   const int ntm = (int)((p.M + 255) / 256), ntn = (int)((p.N + bnu - 1) / bnu);
-  hipLaunchKernelGGL(abl == 1 ? ka : abl == 2 ? kb : abl == 5 ? ke : abl == 6 ? kf : (bnu == 192 ? k3 : k0),
+  hipLaunchKernelGGL(st == 4 ? (abl == 1 ? p1 : bnu == 192 ? p3 : p0) : st == 3 ? (abl == 1 ? c1 : abl == 2 ? c2 : abl == 7 ? c7 : c0) : abl == 1 ? ka : abl == 2 ? kb : abl == 5 ? ke : abl == 6 ? kf :
+                     st == 1 ? (bnu == 192 ? s13 : s10) : st == 2 ? (bnu == 192 ? s23 : s20) : (bnu == 192 ? k3 : k0),
                      dim3((unsigned)(ntm * ntn), (unsigned)batch), dim3(512), LDS256, s, p, ntn, ntm * ntn);
   GSTVD_LAUNCH_CHECK();
   return 0;
@@ -368,16 +447,26 @@ int gemm_dma256_dispatch(const GemmP& p, int64_t batch, int akm, int bkm, int ou
 template <typename OT, bool AKM, bool BKM>
 static int grouped256(const gstvd_gemm_t* tab, const int* off, int nprob, int total, hipStream_t s) {
   auto k0 = gemm_dma256_grouped_kernel<OT, AKM, BKM, 0>;
-  static int attr_rc = ensure_lds(k0, LDS256);
+  auto k1 = gemm_dma256_grouped_kernel<OT, AKM, BKM, 0, 1>;
+  auto k2 = gemm_dma256_grouped_kernel<OT, AKM, BKM, 0, 2>;
+  auto k4 = gemm_dma256_grouped_kernel<OT, AKM, BKM, 0, 4>;
+  static int attr_rc = ensure_lds(k0, LDS256) | ensure_lds(k1, LDS256) | ensure_lds(k2, LDS256) | ensure_lds(k4, LDS256);
   if (attr_rc) return attr_rc;
+  static const int st = [] { const char* e = getenv("GSTVD_GEMM_ST"); return e ? atoi(e) : 0; }();
   // tiles per XCD chunk = 2^chs (default 8: measured best of 1..128 inside the step); GSTVD_GROUP_CHUNK_LOG2 overrides for tuning runs
   static const int chs = [] { const char* e = getenv("GSTVD_GROUP_CHUNK_LOG2"); const int v = e ? atoi(e) : 3; return v < 0 ? 0 : (v > 10 ? 10 : v); }();
-  hipLaunchKernelGGL(k0, dim3((unsigned)total), dim3(512), LDS256, s, tab, off, nprob, total, chs);
+  hipLaunchKernelGGL(st == 1 ? k1 : st == 2 ? k2 : st == 4 ? k4 : k0, dim3((unsigned)total), dim3(512), LDS256, s, tab, off, nprob, total, chs);
   GSTVD_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int gstvd_gemm_group_tile(void) { return 256; }
+
+extern "C" int gstvd_debug_gemm_clock(uint64_t* out_host, int32_t n_words) {
+  if (!out_host || n_words <= 0 || n_words > 512 * 4) return GSTVD_E_SHAPE;
+  hipError_t e = hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_clk256), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost);
+  return e == hipSuccess ? 0 : (int)e;
+}
 
 extern "C" int gstvd_gemm_grouped(const gstvd_gemm_t* table_dev, const int32_t* tile_off_dev, int64_t nprob, int64_t total_tiles,
                                   int32_t dtype_in, int32_t dtype_out, int32_t a_kmajor, int32_t b_kmajor, gstvd_stream_t stream) {

@@ -236,6 +236,12 @@ int gstvd_adamw_bf16grad(float* param, const void* grad_bf16, int64_t grad_origi
                          int64_t n, const int64_t* seg_end, const float* hp, int64_t nseg, float beta1, float beta2, float eps,
                          const float* step, float grad_scale, int64_t begin, gstvd_stream_t s);
 
+/* Diagnostic (never on the product path): copies the in-kernel clock stamps that the GSTVD_GEMM_ST=3 build of the 256x256 GEMM
+ * tile leaves behind -- per workgroup {shader-clock ticks, 100 MHz wall ticks, K steps, 0} around its K loop -- to host memory.
+ * Evidence for DESIGN.md's "what clock does an MFMA-dense loop hold" (MI355X_MICROARCH.md, DVFS give-back item 6); replaces
+ * nothing in the reference. */
+int gstvd_debug_gemm_clock(uint64_t* out_host, int32_t n_words);
+
 #ifdef __cplusplus
 }
 #endif

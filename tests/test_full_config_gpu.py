@@ -123,3 +123,58 @@ def test_bench_shape_step_properties():
     model.eval()
     l2, _ = model(**batch)
     assert torch.isfinite(l2) and l2.item() < l1.item() + 0.5
+
+
+def test_full_size_candidate_chunk_properties(full_fp32):
+    """BASELINE configs[3], scoring half at FULL size: one evaluate_gen chunk = 5 rounds x 100 candidates = 500 decoder rows
+    (evaluate_gen.py:30,84) through score_candidates on the 388 M-parameter model, checked by size-independent properties:
+      * encode-once scores == the expanded per-row path (every candidate row with its own encoder pass) on a slice of rows;
+      * a sampled subset equals the CPU oracle's evaluate_gen arithmetic (expanded rows, fp32) within 2e-3;
+      * permuting the candidates of a round permutes its scores and nothing else (rows are independent);
+      * duplicated candidates score identically, and every score is a finite log-probability sum <= 0."""
+    import bench
+    from gst_visdial_amd.config import bert_base_enc_config, bert_base_dec_config
+    model, _, sd, _, _, _ = full_fp32
+    O = _oracle()
+    mode = model.params["mode"]
+    model.params["mode"] = "vd_eval_val"
+    try:
+        E, G, T, U = 5, 100, 256, 25
+        V = model.decoder.config.vocab_size
+        rows = bench.synthetic_rows(E, T, 37, U, 2048, V, 77, DEV)
+        cand = bench.synthetic_rows(E * G, 8, 37, U, 2048, V, 78, DEV)            # only its decoder side is used
+        dec = cand["dec_input_ids"].clone()
+        alen = (dec != 0).sum(-1)
+        dec[torch.arange(E * G, device=DEV), alen.clamp(max=U - 1)] = 102         # eval rows end in [SEP] (dataloader_visdial_gen.py:230)
+        dec[7] = dec[3]                                                            # a duplicated candidate inside round 0
+        dmask = cand["dec_attention_mask"]
+        enc = (rows["enc_image_features"], rows["enc_image_spatials"], rows["enc_image_mask"], rows["enc_input_ids"],
+               rows["enc_segments"], rows["enc_attention_mask"])
+        with torch.no_grad():
+            fast = model.score_candidates(*enc, dec, dmask, G).clone()
+            assert fast.shape == (E * G,) and torch.isfinite(fast).all() and (fast <= 0).all()
+            assert fast[7].item() == fast[3].item()
+            # per-row path on 12 rows spread over the rounds
+            pick = torch.tensor([0, 3, 7, 99, 100, 157, 250, 299, 300, 420, 498, 499], device=DEV)
+            rnd = pick // G
+            slow = model.score_candidates(*(t[rnd] for t in enc), dec[pick], dmask[pick], 1)
+            assert (fast[pick] - slow).abs().max().item() < 2e-4 * max(1.0, slow.abs().max().item())
+            # candidate permutation inside every round
+            perm = torch.stack([torch.randperm(G, generator=torch.Generator().manual_seed(r)) for r in range(E)]).to(DEV)
+            idx = (torch.arange(E, device=DEV)[:, None] * G + perm).reshape(-1)
+            shuffled = model.score_candidates(*enc, dec[idx], dmask[idx], G)
+            assert (shuffled - fast[idx]).abs().max().item() < 1e-4
+        # oracle on 4 of the rows (expanded the reference's way)
+        sub = pick[[0, 4, 8, 11]]
+        r4 = (sub // G).cpu()
+        cpu = dict(enc_image_features=rows["enc_image_features"].cpu()[r4], enc_image_spatials=rows["enc_image_spatials"].cpu()[r4],
+                   enc_image_mask=rows["enc_image_mask"].cpu()[r4], enc_input_ids=rows["enc_input_ids"].cpu()[r4],
+                   enc_segments=rows["enc_segments"].cpu()[r4], enc_attention_mask=rows["enc_attention_mask"].cpu()[r4],
+                   dec_input_ids=dec[sub].cpu().clone(), dec_attention_mask=dmask[sub].cpu(), dec_labels=None)
+        unmutated = cpu["dec_input_ids"].clone()
+        torch.set_num_threads(min(os.cpu_count() or 1, 16))
+        out = O.model_forward(sd, bert_base_enc_config(), bert_base_dec_config(), cpu)
+        ref = O.answer_scores(out["logits"], unmutated)
+        assert (fast[sub].cpu() - ref).abs().max().item() < 2e-3 * max(1.0, ref.abs().max().item())
+    finally:
+        model.params["mode"] = mode
