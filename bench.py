@@ -109,9 +109,29 @@ def cpu_baseline(model, T, R, U, F, V, rows=2):
     if dt < 8.0:                                   # size the real sample for ~15 s of CPU work (cap 32 rows)
         n = max(2, min(48, int(22.0 / max(dt, 1e-3))))
         dt = one(n, T)
-    return {"value": n / dt, "unit": "dialog-rounds/sec", "cores": threads, "kind": "port",
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "unknown")
+    except OSError:
+        pass
+    return {"value": n / dt, "unit": "dialog-rounds/sec", "cores": threads, "kind": "port", "cpu_model": cpu_model,
+            "host_logical_cpus": os.cpu_count(),
             "sample": "%d row(s) x 1 train step (fwd+loss+bwd, fp32, T=%d R=%d U=%d) of oracle/vd_oracle.py on %d threads; %.1f s"
                       % (n, T, R, U, threads, dt)}
+
+
+def demangle(sym):
+    """Best effort (llvm-cxxfilt from the ROCm tree / c++filt); the mangled symbol is what rocprofv3 traces key on."""
+    import shutil
+    import subprocess
+    for exe in ("/opt/rocm/lib/llvm/bin/llvm-cxxfilt", shutil.which("c++filt")):
+        if exe and os.path.exists(exe):
+            try:
+                return subprocess.run([exe, sym], stdout=subprocess.PIPE, timeout=10).stdout.decode().strip()
+            except Exception:       # noqa: BLE001
+                pass
+    return None
 
 
 def _flush_c_stdio():
@@ -142,6 +162,8 @@ def main():
     ap.add_argument("--chunk-melems", type=int, default=0,
                     help="backward-pipeline slice size in Mi elements (0 = auto: 192 at N=1, 40 at N>1)")
     ap.add_argument("--no-streams", action="store_true", help="run the vision stream on the main HIP stream")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 parity-mode timing beside the bf16 headline")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive measurement (inputs staged from pinned host memory)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -323,7 +345,7 @@ def main():
             agg = prof.summary()
         finally:
             eng.use_streams, eng.pipe = saved
-        gemms = {k: v for k, v in agg.items() if k.startswith("gemm_")}
+        gemms = {k[5:]: v for k, v in agg.items() if k.startswith("gemm:")}      # keyed by the launched kernel's mangled symbol
         # Dominant kernel = the GEMM instantiation with the largest total duration in this step, measured live with HIP
         # events on the stream each launch goes to (the committed rocprofv3 stats of the same command rank the same
         # kernels on top: profiles/r01_kernel_stats_bench.csv).  The next two are listed beside it.
@@ -333,21 +355,24 @@ def main():
         ach = dv["flops"] / (dv["ms"] * 1e-3) / 1e12
         all_gemm_flops = sum(v["flops"] for v in gemms.values())
         all_gemm_ms = sum(v["ms"] for v in gemms.values())
-        pmc_key = lambda tag: ("gemm_grouped_wgrad_256" if "grouped" in tag else "gemm_dma256" if tag.endswith("_256")
-                               else "gemm_dma128" if tag.endswith("_128") else "gemm_dma64")
-        traffic = None
-        try:       # HBM bytes per launch from the PMC passes (tools/pmc_bench.sh; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
-                   # averaged over the launches of the same tile class
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                traffic = json.load(f).get(pmc_key(dom), {}).get("hbm_bytes_per_launch")
-        except (OSError, ValueError):
-            pass
+        pmc_key = lambda sym: ("gemm_grouped_wgrad_256" if "grouped" in sym else "gemm_dma256" if "gemm_dma256" in sym
+                               else "gemm_dma128" if "Li128ELi128E" in sym else "gemm_dma64")
+        traffic, traffic_src = None, None
+        for fn in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            try:   # HBM bytes per launch from the committed PMC passes (tools/pmc_bench.sh; FETCH_SIZE x2 gfx950 correction +
+                   # WRITE_SIZE): an average over the launches of the same tile CLASS, read from a file -- not measured in this run
+                with open(os.path.join(ROOT, "profiles", fn)) as f:
+                    traffic = json.load(f).get(pmc_key(dom), {}).get("hbm_bytes_per_launch")
+                traffic_src = "profiles/%s (tile-class average of a separate rocprofv3 --pmc run)" % fn
+                break
+            except (OSError, ValueError):
+                continue
         others = [{"kernel": k, "achieved": round(gemms[k]["flops"] / (gemms[k]["ms"] * 1e-3) / 1e12, 2),
                    "frac": round(gemms[k]["flops"] / (gemms[k]["ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                    "ms_per_step": round(gemms[k]["ms"], 3)} for k in order[1:3]]
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                    "kernel": dom, "launches_per_step": dv["launches"],
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "kernel": dom, "kernel_demangled": demangle(dom), "launches_per_step": dv["launches"],
                     "flops_per_launch": dv["flops"] / dv["launches"], "avg_launch_us": round(1e3 * dv["ms"] / dv["launches"], 2),
                     "algorithmic_bytes_per_launch": (dv["bytes"] / dv["launches"]) if dv["bytes"] else None,
                     "all_gemm_tflops": round(all_gemm_flops / (all_gemm_ms * 1e-3) / 1e12, 2),
@@ -366,6 +391,62 @@ def main():
                    for k, v in sorted(shapes.items(), key=lambda kv: -kv[1]["ms"])}
             with open(args.breakdown_json, "w") as f:
                 json.dump({"ms_per_step": ms_step, "kernels": breakdown, "shapes": shp}, f, indent=1)
+
+    # ---- PCIe-inclusive rate (reported beside `value`, never as `value`): every step's rows come from pageable host memory
+    # through step.PinnedStager (pinned slots, copy stream, one batch ahead) and are refreshed IN PLACE into the tensors the
+    # captured graph reads
+    pcie = None
+    if rank == 0 and world == 1 and not args.no_h2d:
+        from gst_visdial_amd.step import PinnedStager
+        stager = PinnedStager(device, depth=2)
+        host_rows = [{k: v.cpu() for k, v in synthetic_rows(B, T, R, U, F, V, 4000 + i, "cpu").items()} for i in range(3)]
+        nb = sum(v.numel() * v.element_size() for v in host_rows[0].values())
+
+        def h2d_steps(n):
+            pending = stager.fill(host_rows[0])
+            for i in range(n):
+                rows = stager.upload(pending)
+                for k, v in rows.items():
+                    batch[k].copy_(v)
+                step()
+                pending = stager.fill(host_rows[(i + 1) % 3])          # host half of the next batch under this step's replay
+            stager.upload(pending)
+        h2d_steps(2)
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        n_h2d = max(5, min(args.steps, 20))
+        h2d_steps(n_h2d)
+        torch.cuda.synchronize()
+        dth = time.perf_counter() - th
+        pcie = {"value": round(B * n_h2d / dth, 3), "unit": "dialog-rounds/sec", "ms_per_step": round(dth * 1e3 / n_h2d, 3),
+                "host_bytes_per_step": nb, "how": "pageable host rows -> pinned slots (host fill one batch ahead, under the replay) -> "
+                "blocking H2D -> in-place refresh of the captured graph's inputs (gst_visdial_amd.step.PinnedStager)"}
+
+    # ---- the parity mode's cost: the same step with every GEMM on the exact-fp32 MFMA (what the 1e-4 logit tolerance is
+    # tested in); eager issue, a few steps
+    fp32_ms = None
+    if rank == 0 and world == 1 and not args.no_fp32 and args.precision == "bf16":
+        try:
+            m32, _ = build_model(device, "fp32", seed=1234, streams=not args.no_streams)
+            m32.train()
+            o32 = FusedAdamW(m32, lr=2e-5, warmup_steps=1500, t_total=100000)
+
+            def s32():
+                l32, _ = m32(**batch)
+                l32.backward()
+                o32.step()
+                o32.zero_grad()
+            s32(); s32()
+            torch.cuda.synchronize()
+            t32 = time.perf_counter()
+            for _ in range(3):
+                s32()
+            torch.cuda.synchronize()
+            fp32_ms = round((time.perf_counter() - t32) * 1e3 / 3, 2)
+            del m32, o32
+            torch.cuda.empty_cache()
+        except Exception as ex:            # noqa: BLE001 -- a diagnostic beside the headline must not take the line down
+            sys.stderr.write("bench: fp32 parity-mode timing skipped (%s: %s)\n" % (type(ex).__name__, ex))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -387,6 +468,8 @@ def main():
         if breakdown is not None:
             out["kernel_breakdown_ms"] = {k: v["ms"] for k, v in list(breakdown.items())[:12]}
         out["config"]["grad_allreduce_dtype"] = (compress or "fp32") if world > 1 else None
+        out["config"]["fp32_parity_mode_ms_per_step"] = fp32_ms
+        out["config"]["pcie_inclusive"] = pcie
     if world > 1 or force_dist:
         import torch.distributed as dist
         dist.barrier()

@@ -72,6 +72,8 @@ SIGNATURES = {
     "gstvd_gemm_splitk": (_i32, [_vp, _i32, _vp, _i64, _vp]),
     "gstvd_gemm_group_tile": (_i32, []),
     "gstvd_debug_gemm_clock": (_i32, [_vp, _i32]),
+    "gstvd_gemm_kernel_name": (_i32, [C.POINTER(GemmDesc), _i32, C.c_char_p, _i32]),
+    "gstvd_gemm_grouped_kernel_name": (_i32, [_i32, _i32, _i32, _i32, C.c_char_p, _i32]),
     "gstvd_gemm_grouped": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp]),
     "gstvd_ln_fwd": (_i32, [C.POINTER(LnDesc), _vp]),
     "gstvd_ln_bwd_blocks": (_i64, [_i64]),

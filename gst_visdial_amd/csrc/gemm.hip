@@ -105,7 +105,7 @@ static int launch_cfg(const GemmP& p, int64_t batch, hipStream_t s) {
   static int attr_rc = ensure_lds(k, lds);
   if (attr_rc) return attr_rc;
   dim3 grid((unsigned)((p.N + BN - 1) / BN), (unsigned)((p.M + BM - 1) / BM), (unsigned)batch);
-  hipLaunchKernelGGL(k, grid, dim3(WM * WN * 64), lds, s, p);
+  GSTVD_LAUNCH(k, grid, dim3(WM * WN * 64), lds, s, p);
   GSTVD_LAUNCH_CHECK();
   return 0;
 }
@@ -125,6 +125,8 @@ static int launch_dtype(const GemmP& p, int64_t batch, int akm, int bkm, hipStre
   if (akm && bkm) return launch_layout<T, OT, true, true>(p, batch, s);
   return launch_layout<T, OT, true, false>(p, batch, s);
 }
+
+thread_local const void** gstvd_plan_capture = nullptr;
 
 static int gemm_params(const gstvd_gemm_t* g, GemmP& p) {
   if (!g || !g->A || !g->B || !g->C) return GSTVD_E_NULL;
@@ -160,6 +162,25 @@ extern "C" int gstvd_gemm_splitk(const gstvd_gemm_t* g, int32_t splits, void* ws
   if (g->dtype_in != GSTVD_BF16 || g->batch != 1) return GSTVD_E_UNSUPPORTED;
   if (g->dtype_out != GSTVD_BF16 && g->dtype_out != GSTVD_F32) return GSTVD_E_DTYPE;
   return gemm_dma_splitk_dispatch(p, g->a_kmajor, g->b_kmajor, g->dtype_out == GSTVD_F32, splits, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// Which kernel would gstvd_gemm (splits <= 1) / gstvd_gemm_splitk (splits >= 2) launch for this problem?  Writes the device
+// function's (mangled) symbol name into buf.  Nothing is launched, no memory is touched.
+extern "C" int gstvd_gemm_kernel_name(const gstvd_gemm_t* g, int32_t splits, char* buf, int32_t buf_len) {
+  if (!g || !buf || buf_len <= 1) return GSTVD_E_NULL;
+  const void* fn = nullptr;
+  gstvd_plan_capture = &fn;
+  static char dummy_ws[16];
+  const int rc = splits >= 2 ? gstvd_gemm_splitk(g, splits, dummy_ws, (int64_t)1 << 40, nullptr) : gstvd_gemm(g, nullptr);
+  gstvd_plan_capture = nullptr;
+  if (rc) return rc;
+  if (!fn) return GSTVD_E_UNSUPPORTED;
+  const char* name = hipKernelNameRefByPtr(fn, nullptr);
+  if (!name) return GSTVD_E_UNSUPPORTED;
+  int i = 0;
+  for (; name[i] && i < buf_len - 1; ++i) buf[i] = name[i];
+  buf[i] = 0;
+  return 0;
 }
 
 extern "C" int gstvd_gemm(const gstvd_gemm_t* g, gstvd_stream_t stream) {

@@ -224,6 +224,17 @@ DEVFN void gemm_epilogue_rows(const GemmP& p, const DropKey& dk, const f32x4 (&a
   }
 }
 
+// Plan-only mode of the GEMM entry points (gstvd_gemm_kernel_name): the dispatch runs exactly as for a launch, but the launch
+// site records the host-side kernel handle it WOULD have launched instead of launching it.  bench.py reports the launched
+// symbol from this -- the dispatch itself is the single source of truth, not a host-side re-derivation of its rule.
+extern thread_local const void** gstvd_plan_capture;
+#define GSTVD_LAUNCH(kern, grid, block, lds, stream, ...)                                              \
+  do {                                                                                                 \
+    auto k_ = (kern);                                                                                  \
+    if (gstvd_plan_capture) *gstvd_plan_capture = (const void*)k_;                                     \
+    else hipLaunchKernelGGL(k_, grid, block, lds, stream, __VA_ARGS__);                                \
+  } while (0)
+
 template <typename K> static int ensure_lds(K kernel, int bytes) {
   if (bytes <= 48 * 1024) return 0;
   hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);

@@ -214,7 +214,7 @@ static int dma_launch(const GemmP& p, int64_t batch, hipStream_t s) {
   static int attr_rc = ensure_lds(k, lds);
   if (attr_rc) return attr_rc;
   const int ntm = (int)((p.M + BM - 1) / BM), ntn = (int)((p.N + BNU - 1) / BNU);
-  hipLaunchKernelGGL(k, dim3((unsigned)(ntm * ntn), (unsigned)batch), dim3(WM * WN * 64), lds, s, p, ntn, ntm * ntn);
+  GSTVD_LAUNCH(k, dim3((unsigned)(ntm * ntn), (unsigned)batch), dim3(WM * WN * 64), lds, s, p, ntn, ntm * ntn);
   GSTVD_LAUNCH_CHECK();
   return 0;
 }
@@ -264,7 +264,7 @@ static int splitk_launch(const GemmP& p, int S, void* ws, int64_t ws_bytes, hipS
   if (tiles > SPLITK_MAX_TILES) return GSTVD_E_SHAPE;
   int* cnt = (int*)ws;                                                   // [tiles] arrival counters (zero between launches)
   float* part = (float*)((char*)ws + SPLITK_MAX_TILES * 4);             // fixed layout: a scratch serves launches of any shape
-  hipLaunchKernelGGL(k, dim3((unsigned)(tiles * S)), dim3(256), lds, s, p, ntn, tiles, S, part, cnt);
+  GSTVD_LAUNCH(k, dim3((unsigned)(tiles * S)), dim3(256), lds, s, p, ntn, tiles, S, part, cnt);
   GSTVD_LAUNCH_CHECK();
   return 0;
 }

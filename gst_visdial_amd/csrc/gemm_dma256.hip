@@ -407,7 +407,7 @@ static int launch256(const GemmP& p, int64_t batch, int niu, hipStream_t s) {
   static const int st = [] { const char* e = getenv("GSTVD_GEMM_ST"); return e ? atoi(e) : 0; }();
   const int bnu = (niu == 3 && abl == 0) ? 192 : 256;
   const int ntm = (int)((p.M + 255) / 256), ntn = (int)((p.N + bnu - 1) / bnu);
-  hipLaunchKernelGGL(st == 4 ? (abl == 1 ? p1 : bnu == 192 ? p3 : p0) : st == 3 ? (abl == 1 ? c1 : abl == 2 ? c2 : abl == 7 ? c7 : c0) : abl == 1 ? ka : abl == 2 ? kb : abl == 5 ? ke : abl == 6 ? kf :
+  GSTVD_LAUNCH(st == 4 ? (abl == 1 ? p1 : bnu == 192 ? p3 : p0) : st == 3 ? (abl == 1 ? c1 : abl == 2 ? c2 : abl == 7 ? c7 : c0) : abl == 1 ? ka : abl == 2 ? kb : abl == 5 ? ke : abl == 6 ? kf :
                      st == 1 ? (bnu == 192 ? s13 : s10) : st == 2 ? (bnu == 192 ? s23 : s20) : (bnu == 192 ? k3 : k0),
                      dim3((unsigned)(ntm * ntn), (unsigned)batch), dim3(512), LDS256, s, p, ntn, ntm * ntn);
   GSTVD_LAUNCH_CHECK();
@@ -455,12 +455,31 @@ static int grouped256(const gstvd_gemm_t* tab, const int* off, int nprob, int to
   static const int st = [] { const char* e = getenv("GSTVD_GEMM_ST"); return e ? atoi(e) : 0; }();
   // tiles per XCD chunk = 2^chs (default 8: measured best of 1..128 inside the step); GSTVD_GROUP_CHUNK_LOG2 overrides for tuning runs
   static const int chs = [] { const char* e = getenv("GSTVD_GROUP_CHUNK_LOG2"); const int v = e ? atoi(e) : 3; return v < 0 ? 0 : (v > 10 ? 10 : v); }();
-  hipLaunchKernelGGL(st == 1 ? k1 : st == 2 ? k2 : st == 4 ? k4 : k0, dim3((unsigned)total), dim3(512), LDS256, s, tab, off, nprob, total, chs);
+  GSTVD_LAUNCH(st == 1 ? k1 : st == 2 ? k2 : st == 4 ? k4 : k0, dim3((unsigned)total), dim3(512), LDS256, s, tab, off, nprob, total, chs);
   GSTVD_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int gstvd_gemm_group_tile(void) { return 256; }
+
+// symbol of the grouped kernel for a (dtype, layout) combination -- same plan-only mechanism as gstvd_gemm_kernel_name
+extern "C" int gstvd_gemm_grouped_kernel_name(int32_t dtype_in, int32_t dtype_out, int32_t a_kmajor, int32_t b_kmajor, char* buf,
+                                              int32_t buf_len) {
+  if (!buf || buf_len <= 1) return GSTVD_E_NULL;
+  const void* fn = nullptr;
+  static gstvd_gemm_t dummy_tab;
+  static int32_t dummy_off;
+  gstvd_plan_capture = &fn;
+  const int rc = gstvd_gemm_grouped(&dummy_tab, &dummy_off, 1, 1, dtype_in, dtype_out, a_kmajor, b_kmajor, nullptr);
+  gstvd_plan_capture = nullptr;
+  if (rc) return rc;
+  const char* name = fn ? hipKernelNameRefByPtr(fn, nullptr) : nullptr;
+  if (!name) return GSTVD_E_UNSUPPORTED;
+  int i = 0;
+  for (; name[i] && i < buf_len - 1; ++i) buf[i] = name[i];
+  buf[i] = 0;
+  return 0;
+}
 
 extern "C" int gstvd_debug_gemm_clock(uint64_t* out_host, int32_t n_words) {
   if (!out_host || n_words <= 0 || n_words > 512 * 4) return GSTVD_E_SHAPE;

@@ -89,6 +89,21 @@ def gemm_tag(dtype_in, a_km, b_km, M, N, batch):
     return "gemm_%s_%s_%d" % ("bf16" if dtype_in == BF16 else "f32", lay, tile)
 
 
+_KNAME = {}
+
+
+def gemm_kernel_symbol(d, splits=1):
+    """(Mangled) symbol of the device kernel the library launches for descriptor `d` -- asked of the library's own dispatch
+    (gstvd_gemm_kernel_name), cached by everything the dispatch looks at."""
+    key = (d.M, d.N, d.K, d.batch, d.dtype_in, d.dtype_out, d.a_kmajor, d.b_kmajor, splits, d.ldc % 8, d.epilogue & ~0)
+    name = _KNAME.get(key)
+    if name is None:
+        buf = C.create_string_buffer(512)
+        L.check("gstvd_gemm_kernel_name", L.load().gstvd_gemm_kernel_name(C.byref(d), splits, buf, 512))
+        name = _KNAME[key] = buf.value.decode()
+    return name
+
+
 class Rng:
     """Device-resident (seed, offset) pair read by every dropout site; graph-capture safe."""
 
@@ -135,10 +150,10 @@ def gemm(A, B, C_out, M, N, K, *, a_km=False, b_km=False, bias=None, addend=None
     if splits > 1:
         ws = _splitk_scratch(A.device)
         L.check("gstvd_gemm_splitk", lib.gstvd_gemm_splitk(C.byref(d), splits, ws.data_ptr(), ws.numel(), _stream()))
-        tag = gemm_tag(d.dtype_in, a_km, b_km, M, N, batch) + "_splitk%d" % splits
     else:
         L.check("gstvd_gemm", lib.gstvd_gemm(C.byref(d), _stream()))
-        tag = gemm_tag(d.dtype_in, a_km, b_km, M, N, batch)
+    # profiling: the record is keyed by the symbol the library really launched (one per template instantiation)
+    tag = ("gemm:" + gemm_kernel_symbol(d, splits)) if e0 is not None else None
     _prof_end(e0, tag, 2.0 * M * N * K * batch,
               float(batch) * ((M * K + N * K) * A.element_size() + M * N * C_out.element_size()), (M, N, K, batch))
     return C_out
@@ -234,7 +249,15 @@ class GemmGroup(object):
         e0 = _prof_begin()
         L.check("gstvd_gemm_grouped", lib.gstvd_gemm_grouped(tab.data_ptr(), off.data_ptr(), n, tiles, self.dtype_in, self.dtype_out,
                                                              int(self.a_km), int(self.b_km), _stream()))
-        _prof_end(e0, "gemm_grouped_%s" % ("tn" if self.a_km else "nt"), flops, nbytes, (n, tiles))
+        if e0 is not None:
+            key = ("grouped", self.dtype_in, self.dtype_out, self.a_km, self.b_km)
+            name = _KNAME.get(key)
+            if name is None:
+                buf = C.create_string_buffer(512)
+                L.check("gstvd_gemm_grouped_kernel_name", lib.gstvd_gemm_grouped_kernel_name(self.dtype_in, self.dtype_out, int(self.a_km),
+                                                                                           int(self.b_km), buf, 512))
+                name = _KNAME[key] = buf.value.decode()
+            _prof_end(e0, "gemm:" + name, flops, nbytes, (n, tiles))
         self.items = []
 
 

@@ -236,6 +236,12 @@ int gstvd_adamw_bf16grad(float* param, const void* grad_bf16, int64_t grad_origi
                          int64_t n, const int64_t* seg_end, const float* hp, int64_t nseg, float beta1, float beta2, float eps,
                          const float* step, float grad_scale, int64_t begin, gstvd_stream_t s);
 
+/* Measurement support: the (mangled) symbol of the device kernel that gstvd_gemm (splits <= 1) or gstvd_gemm_splitk
+ * (splits >= 2) would launch for this descriptor -- the dispatch runs, the launch is replaced by recording its target.
+ * bench.py's roofline.kernel comes from here.  Nothing is launched; pointers in the descriptor are not dereferenced. */
+int gstvd_gemm_kernel_name(const gstvd_gemm_t* g, int32_t splits, char* buf, int32_t buf_len);
+int gstvd_gemm_grouped_kernel_name(int32_t dtype_in, int32_t dtype_out, int32_t a_kmajor, int32_t b_kmajor, char* buf, int32_t buf_len);
+
 /* Diagnostic (never on the product path): copies the in-kernel clock stamps that the GSTVD_GEMM_ST=3 build of the 256x256 GEMM
  * tile leaves behind -- per workgroup {shader-clock ticks, 100 MHz wall ticks, K steps, 0} around its K loop -- to host memory.
  * Evidence for DESIGN.md's "what clock does an MFMA-dense loop hold" (MI355X_MICROARCH.md, DVFS give-back item 6); replaces

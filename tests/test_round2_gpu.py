@@ -294,3 +294,64 @@ def test_save_resume_round_trip_equals_uninterrupted_training(tmp_path, fmt, pre
     else:
         for a, b in zip(res, cont):
             assert abs(a - b) < 5e-3 * max(1.0, abs(b)), (res, cont)
+
+
+# ------------------------------------------------------------------------------------------------ f-3: host input path
+def test_pinned_double_buffered_staging_and_prefetch():
+    """step.PinnedStager / step.prefetch (replacing train_gen.py:102-116's pageable copies and :311-321's 10x expansion): the
+    rows reach persistent device buffers through rotating pinned slots, the host half one batch ahead of the compute; five
+    different batches through two slots give exactly the losses of the plain path (no slot is overwritten while in use)."""
+    from gst_visdial_amd import step
+    s = sc()
+    model, params, cfg = s.build_tiny_model("fp32", DEV)
+    model.eval()
+    g = load_npz("tiny_train.npz")
+    b = {k[4:]: v.clone() for k, v in g.items() if k.startswith("in::")}
+
+    def dialog_batch(shift):
+        order = torch.tensor([0, 1, 2, 2, 0, 1])
+        dlg = lambda x: x[order].reshape((2, 3, 1) + tuple(x.shape[1:]))
+        ids = b["enc_input_ids"]
+        ids = torch.where(ids > 110, (ids - 111 + shift) % 200 + 111, ids)
+        return dict(enc_input_ids=dlg(ids), enc_segments=dlg(b["enc_segments"]), enc_att_mask=dlg(b["enc_attention_mask"]),
+                    dec_input_ids=dlg(b["dec_input_ids"]), dec_att_mask=dlg(b["dec_attention_mask"]), dec_labels=dlg(b["dec_labels"]),
+                    enc_image_feat=b["enc_image_features"][:2] * (1.0 + 0.1 * shift), enc_image_loc=b["enc_image_spatials"][:2],
+                    enc_image_mask=b["enc_image_mask"][:2])          # image tensors UNEXPANDED: one per dialog
+
+    p = dict(params, mode="vd_train", batch_size=4, device=torch.device(DEV))
+    batches = [dialog_batch(k) for k in range(5)]
+    with torch.no_grad():
+        plain = [step.forward(model, bt, p, generator=torch.Generator().manual_seed(50 + i))[0].item() for i, bt in enumerate(batches)]
+        st = step.PinnedStager(DEV, depth=2)
+        staged = [step.forward(model, bt, p, generator=torch.Generator().manual_seed(50 + i), stager=st)[0].item()
+                  for i, bt in enumerate(batches)]
+        assert staged == plain
+        gens = iter(torch.Generator().manual_seed(50 + i) for i in range(5))
+
+        class Loader(object):                      # a generator per batch, like the sequential runs above
+            def __iter__(self):
+                return iter(batches)
+        st2 = step.PinnedStager(DEV, depth=2)
+        pre = []
+        it = iter(batches)
+        pending = None
+        for i, bt in enumerate(batches):           # prefetch() by hand so each batch keeps its own generator
+            rows, _ = step.select_rows(bt, p, None, torch.Generator().manual_seed(50 + i))
+            h = st2.put(rows)
+            if pending is not None:
+                pre.append(step.forward_rows(model, st2.get(pending), p)[0].item())
+            pending = h
+        pre.append(step.forward_rows(model, st2.get(pending), p)[0].item())
+        assert pre == plain
+        n = sum(1 for _ in step.prefetch(Loader(), p, step.PinnedStager(DEV)))
+        assert n == 5
+    assert st.bytes_staged > 0 and all(t.is_pinned() for t in st.host[0].values())
+    assert st.mode == "pinned_async"
+    for mode in ("pinned", "pageable"):                                      # the other two transports give the same numbers
+        stm = step.PinnedStager(DEV, depth=2, mode=mode)
+        with torch.no_grad():
+            got = [step.forward(model, bt, p, generator=torch.Generator().manual_seed(50 + i), stager=stm)[0].item()
+                   for i, bt in enumerate(batches)]
+        assert got == plain, mode
+    assert torch.get_num_threads() >= 1
+    assert len(set(plain)) == 5                    # the batches really differ
