@@ -302,7 +302,6 @@ class Engine(object):
         self._decode_sessions = {}
         self._last_decode = None
         self.anchor = None
-        self.grad_hook = None          # callable(offset): every gradient at flat offset >= `offset` is final
         self.pipe = None               # BackwardPipeline (pipeline.py): slice-wise wgrad / all-reduce / AdamW on the aux stream
         self.tape, self.rec = [], False
         self.accumulate, self.written = False, set()
@@ -380,29 +379,27 @@ class Engine(object):
 
     def push(self, fn):
         if self.rec:
-            self.tape.append((self.tag, fn))
+            sc = ops.Profiler.scope
+            if sc is not None and ops.Profiler.active is not None:      # instrumented step: backward inherits the block label
+                def scoped(fn=fn, sc=sc):
+                    prev, ops.Profiler.scope = ops.Profiler.scope, sc
+                    try:
+                        fn()
+                    finally:
+                        ops.Profiler.scope = prev
+                self.tape.append((self.tag, scoped))
+            else:
+                self.tape.append((self.tag, fn))
 
     def mark(self, key):
-        if self.rec and (self.grad_hook is not None or self.pipe is not None):
+        if self.rec and self.pipe is not None:
             off = self.flat.marks[key]
             self.tape.append(("t", lambda: self._hook(off)))
 
     def _hook(self, off):
         """Backward reached flat offset `off`: every gradient at offset >= off has been produced or queued."""
-        if self.pipe is not None:
-            if self.pipe.ready(off):
-                self._emit(off)
-            return
-        if self.use_streams:
-            self._wait("t", "v")
-        if self.aux_busy:
-            ev = torch.cuda.Event()
-            ev.record(self.aux)
-            self.main.wait_event(ev)
-            self.aux_busy = False
-        self.wgrads.flush()           # weight / bias / LayerNorm gradients of the finished region must be final first
-        self.colsums.flush()
-        self.grad_hook(off)
+        if self.pipe is not None and self.pipe.ready(off):
+            self._emit(off)
 
     def _emit(self, off):
         """Hand the finished slice [off, pipe.hi) to the backward pipeline on the auxiliary stream."""
@@ -618,6 +615,13 @@ class Engine(object):
         c = self.enc_cfg
         H, Hv, Hb, nh = c.hidden_size, c.v_hidden_size, c.bi_hidden_size, c.bi_num_attention_heads
         d = Hb // nh
+        prev_scope, ops.Profiler.scope = ops.Profiler.scope, "coattn"
+        try:
+            return self._conn_layer(p, xv, xt, Bn, R, T, I, c, H, Hv, Hb, nh, d)
+        finally:
+            ops.Profiler.scope = prev_scope
+
+    def _conn_layer(self, p, xv, xt, Bn, R, T, I, c, H, Hv, Hb, nh, d):
         with self.on("v"):
             qkv1 = self.lin(xv, p + ".qkv1.w", p + ".qkv1.b", 3 * Hb, Hv)
         qkv2 = self.lin(xt, p + ".qkv2.w", p + ".qkv2.b", 3 * Hb, H)
@@ -698,7 +702,7 @@ class Engine(object):
         d = H // nh
         eps = c.layer_norm_eps
         self.mark("dec")
-        if self.rec and self.use_streams and self.grad_hook is None and self.pipe is None:
+        if self.rec and self.use_streams and self.pipe is None:
             self.tape.append(("t", self._flush_aux))      # backward: the decoder's gradients are complete here
         if kv is None:
             kv = self.lin(enc, "dec.ckv.w", "dec.ckv.b", 2 * L * H, H)
@@ -847,8 +851,6 @@ class Engine(object):
             self.aux_busy = False
         self.wgrads.flush()
         self.colsums.flush()
-        if self.grad_hook is not None:
-            self.grad_hook(0)
         for p, gv in zip(flat.live, flat.grad_views):
             p.grad = gv
         fa = st["I"].get("feats_act")

@@ -49,7 +49,15 @@ def _active_collectives():
         return None
 
 
+LAST_QUIESCE = [None]      # how the most recent capture waited for c10d's watchdog: "no-process-group" | "drained" | "timer"
+
+
 def quiesce_before_capture(timeout=20.0):
+    LAST_QUIESCE[0] = _quiesce(timeout)
+    return LAST_QUIESCE[0]
+
+
+def _quiesce(timeout):
     """Call right before a stream capture.  c10d's watchdog thread polls the events of eager collectives until it has seen
     them complete (a pass every ~100 ms).  If a capture starts while such a Work is still on its list, the poll can hit an
     event of the capturing stream: the capture is invalidated (hipErrorStreamCaptureInvalidated) and the watchdog's own

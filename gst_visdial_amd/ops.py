@@ -38,6 +38,7 @@ class Profiler(object):
     """Optional per-launch timing with HIP events on the launch stream (bench.py's kernel breakdown).
     Off by default; `with ops.Profiler() as p:` records (tag, flops, bytes, start, end) per wrapped call."""
     active = None
+    scope = None          # label the engine sets around a block (e.g. "coattn"): carried by every record made inside it
 
     def __init__(self):
         self.records = []
@@ -49,10 +50,13 @@ class Profiler(object):
     def __exit__(self, *a):
         Profiler.active = None
 
-    def summary(self, by_shape=False):
+    def summary(self, by_shape=False, scope=None):
+        """Aggregate by tag; `scope`: only the records made inside that engine block."""
         torch.cuda.synchronize()
         agg = {}
-        for tag, flops, nbytes, e0, e1, detail in self.records:
+        for tag, flops, nbytes, e0, e1, detail, sc in self.records:
+            if scope is not None and sc != scope:
+                continue
             if by_shape and detail is not None:
                 tag = "%s %s" % (tag, "x".join(str(d) for d in detail))
             a = agg.setdefault(tag, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
@@ -76,7 +80,7 @@ def _prof_end(e0, tag, flops=0.0, nbytes=0.0, detail=None):
         return
     e1 = torch.cuda.Event(enable_timing=True)
     e1.record()
-    Profiler.active.records.append((tag, flops, nbytes, e0, e1, detail))
+    Profiler.active.records.append((tag, flops, nbytes, e0, e1, detail, Profiler.scope))
 
 
 def gemm_tag(dtype_in, a_km, b_km, M, N, batch):

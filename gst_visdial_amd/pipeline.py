@@ -10,6 +10,12 @@ which -- on the engine's auxiliary stream, i.e. concurrently with the remaining 
     3. the fused AdamW update of P[lo:hi] (+ bf16 shadow weights), with the 1/N scale folded in;
     at N > 1 steps 2-3 ride on a dedicated communication stream so that the aux stream can start the next slice.
 
+It is the ONE gradient-synchronisation path of this package (round 1 also carried a second, hook-based bucketed all-reduce,
+`dp.GradSync`, that duplicated the slicing logic and was not on the bench path; it is gone).  Sizing: xGMI is point to point
+(7 links x ~153 GB/s per GPU), a ring all-reduce is per-link bound, so slices are few and large (graded: 128, 48, 48, 32, 32,
+24 Mi elements at N>1 -- the first, largest one has the whole encoder backward to hide behind, the last ones keep the exposed
+tail short) instead of hundreds of small buckets.
+
 This is the MI355X-native replacement of nn.DataParallel's per-step parameter broadcast + gradient reduce-add
 (train_gen.py:295,324) and of the serial optimizer.step() (train_gen.py:326-329).  loss = mean over ranks of the
 per-rank token mean, exactly DataParallel's gather + .mean() (train_gen.py:134-135).

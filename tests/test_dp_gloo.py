@@ -1,5 +1,6 @@
-"""Data-parallel gradient sync (gst_visdial_amd/dp.py) on CPU with the gloo backend, world_size 2:
-bucketed, backward-ordered all-reduce of the flat gradient buffer == sum over ranks; slices tile [0, n) exactly once."""
+"""Data-parallel gradient sync (gst_visdial_amd/pipeline.py, the one path bench.py uses) on CPU with the gloo backend,
+world_size 2: slice-wise, backward-ordered all-reduce of the flat gradient buffer == sum over ranks; slices tile [0, n)
+exactly once, also with graded slice sizes and with bf16-compressed payloads."""
 import os
 import socket
 
@@ -29,53 +30,77 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, marks, bucket, q):
+def _run_pipe(eng, pipe, marks):
+    pipe.begin()
+    for off in marks:                        # what engine._hook does at every backward watermark
+        if pipe.ready(off):
+            pipe.run_slice(off, pipe.hi)
+    if pipe.hi > 0:
+        pipe.run_slice(0, pipe.hi)
+    pipe.end()
+
+
+def _worker(rank, world, port, n, marks, chunk, compress, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from gst_visdial_amd.dp import GradSync
+    from gst_visdial_amd.pipeline import BackwardPipeline
     eng = _Engine(n, rank)
+    eng.pipe = None
     expect = sum(_Flat(n, r).G for r in range(world))
-    sync = GradSync(eng, bucket_elems=bucket)
-    assert eng.grad_hook is not None
-    sync.begin()
-    for off in marks:                       # backward finishes the flat buffer from the end to the start
-        eng.grad_hook(off)
-    sync.finish()
-    ok = torch.allclose(eng.flat.G, expect, atol=1e-6)
-    q.put((rank, ok, sync.slices))
+    if compress == "bf16":
+        expect = sum(_Flat(n, r).G.to(torch.bfloat16) for r in range(world)).float()
+    pipe = BackwardPipeline(eng, optimizer=None, chunk_elems=chunk, compress=compress)
+    assert pipe.collective and pipe.world == world
+    _run_pipe(eng, pipe, marks)
+    ok = torch.allclose(eng.flat.G, expect, atol=(2e-2 if compress else 1e-6), rtol=(2e-2 if compress else 1e-6))
+    q.put((rank, ok, pipe.slices))
     dist.destroy_process_group()
 
 
-def test_bucketed_allreduce_world2():
-    n, bucket = 10000, 3000
-    marks = [9000, 8200, 7000, 6400, 3000, 2500, 64, 0]
+def _spawn2(target, args):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, marks, bucket, q)) for r in range(2)]
+    procs = [ctx.Process(target=target, args=(r, 2, port) + args + (q,)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, ok, slices in res:
+    return res
+
+
+def test_graded_slices_allreduce_world2():
+    """Graded slice sizes (large first, small last, as bench.py uses at N>1): every slice is one contiguous all-reduce."""
+    n, graded = 10000, [3000, 2000, 1000]
+    marks = [9000, 8200, 7000, 6400, 5000, 4100, 3000, 2500, 1500, 64, 0]
+    for rank, ok, slices in _spawn2(_worker, (n, marks, graded, None)):
         assert ok, "rank %d: all-reduced gradients differ from the sum over ranks" % rank
-        # slices are contiguous, descending, cover [0, n) exactly once, and every bucket but the last is >= bucket
         assert slices[0][1] == n and slices[-1][0] == 0
         for (lo, hi), (lo2, hi2) in zip(slices, slices[1:]):
             assert hi2 == lo
-        assert all(hi - lo >= bucket for lo, hi in slices[:-1])
+        sizes = [hi - lo for lo, hi in slices]
+        assert sizes[0] >= 3000 and sizes[1] >= 2000 and all(x >= 1000 for x in sizes[2:-1])
         assert len(slices) < len(marks)
 
 
-def test_single_process_installs_no_hook():
-    from gst_visdial_amd.dp import GradSync
+def test_bf16_compressed_allreduce_world2():
+    n = 6000
+    for rank, ok, slices in _spawn2(_worker, (n, [5000, 3000, 1000], 1500, "bf16")):
+        assert ok, rank
+
+
+def test_single_process_runs_no_collective():
+    from gst_visdial_amd.pipeline import BackwardPipeline
     eng = _Engine(100, 0)
-    s = GradSync(eng)
-    assert eng.grad_hook is None
-    s.begin(); s.finish()
+    eng.pipe = None
+    before = eng.flat.G.clone()
+    pipe = BackwardPipeline(eng, optimizer=None, chunk_elems=30)
+    assert not pipe.collective and pipe.world == 1 and eng.pipe is pipe
+    _run_pipe(eng, pipe, [80, 50, 10])
+    assert torch.equal(eng.flat.G, before) and pipe.slices[0][1] == 100 and pipe.slices[-1][0] == 0
 
 
 def _pipe_worker(rank, world, port, n, marks, chunk, q):

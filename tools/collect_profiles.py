@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Copy what tools/final_profiles.sh (+ the soak / repro runs) left under gpurun_out/ into profiles/<round>_* (tracked).
+usage: collect_profiles.py r02"""
+import os, shutil, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, dst = os.path.join(root, "gpurun_out", "final"), os.path.join(root, "profiles")
+names = {"bench_n1.json": "bench_n1.json", "breakdown_events.json": "breakdown_events.json", "kernel_stats_bench.csv": "kernel_stats_bench.csv",
+         "serialized_by_kernel_grid.json": "serialized_by_kernel_grid.json", "pmc_traffic.json": "pmc_traffic.json",
+         "pmc_mfma_util.json": "pmc_mfma_util.json", "timeline.txt": "timeline.txt", "gemm_study.txt": "gemm_kloop_study.txt",
+         "h2d_probe.txt": "h2d_probe.txt", "eval_decode.json": "eval_decode.json", "gpu_tests_full.log": "gpu_tests_full.log",
+         "bench_force_dist_rows16.json": "bench_force_dist_rows16.json", "bench_force_dist_rows10.json": "bench_force_dist_rows10.json",
+         "bench_n1_rows10.json": "bench_n1_rows10.json"}
+for a, b in names.items():
+    p = os.path.join(src, a)
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(dst, "%s_%s" % (tag, b)))
+        print("profiles/%s_%s" % (tag, b))
+extra = {"r2/repro_raw.log": "repro_gc_capture_raw.log", "r2/repro_guarded.log": "repro_gc_capture_guarded.log",
+         "r2/repro_rc.log": "repro_gc_capture_rc.log"}
+for a, b in extra.items():
+    p = os.path.join(root, "gpurun_out", a)
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(dst, "%s_%s" % (tag, b)))
+        print("profiles/%s_%s" % (tag, b))

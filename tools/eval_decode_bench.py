@@ -53,6 +53,16 @@ with torch.no_grad():
     tg = timeit(lambda: model(**kw), n=5, warm=2)
     out["sampling_decode_16rows_18steps"] = {"eager_ms": round(te * 1e3, 2), "hipgraph_ms": round(tg * 1e3, 2),
                                              "rows_per_s_hipgraph": round(16 / tg, 1), "speedup": round(te / tg, 2)}
+    # ---- perplexity re-score of the sampled answer (generate.py:183-211): decode state reused vs encoder + decoder again
+    from gst_visdial_amd.generate import answer_perplexity
+    enc_kw = {k: v for k, v in kw.items() if k.startswith("enc_")}
+    def sample_then_ppl(reuse):
+        a = model(**kw)
+        return answer_perplexity(model, enc_kw, a, reuse_decode_state=reuse)
+    tr = timeit(lambda: sample_then_ppl(True), n=5, warm=2)
+    tf = timeit(lambda: sample_then_ppl(False), n=5, warm=2)
+    out["answer_perplexity_16rows"] = {"reusing_decode_state_ms": round((tr - tg) * 1e3, 2), "full_rerun_ms": round((tf - tg) * 1e3, 2),
+                                       "sample_plus_ppl_ms": round(tr * 1e3, 2)}
     kw["ngram_blocking_size"] = 4                             # question generation (generate.py:141): n-gram ban on the device
     tn = timeit(lambda: model(**kw), n=5, warm=2)
     out["sampling_decode_16rows_18steps_ngram4"] = {"hipgraph_ms": round(tn * 1e3, 2), "rows_per_s_hipgraph": round(16 / tn, 1)}

@@ -1,12 +1,36 @@
 #!/bin/bash
-# Regenerates everything under profiles/ that bench.py's JSON line refers to (run on the GPU box; outputs in gpurun_out/final)
+# Regenerates every measurement committed under profiles/ for a round from ONE script (run on the GPU box; outputs go to
+# gpurun_out/final, copy them to profiles/<round>_* afterwards with tools/collect_profiles.py).
+#   bash tools/final_profiles.sh
 export TMPDIR=/tmp; out=gpurun_out/final; rm -rf $out; mkdir -p $out
+# 1. the full GPU test-suite, whole log kept (the driver's command)
+python3 -X faulthandler -m pytest tests/ -x -q -m gpu -p no:cacheprovider --durations=12 > $out/gpu_tests_full.log 2>&1; echo "gpu tests rc=$?" >> $out/gpu_tests_full.log
+# 2. the contract line + per-kernel event breakdown (default flags: CPU baseline, fp32 parity-mode timing, PCIe-inclusive rate)
 python3 bench.py --breakdown-json $out/breakdown_events.json > $out/bench_stdout.log 2> $out/bench_stderr.log
 tail -1 $out/bench_stdout.log > $out/bench_n1.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-breakdown > $out/prof_bench.log 2>&1
-cp $(ls $out/stats/*/*kernel_stats.csv | head -1) $out/kernel_stats_bench.csv
-rm -rf $out/stats
-bash tools/pmc_bench.sh > $out/pmc.log 2>&1
-cp gpurun_out/pmc3/summary.json $out/pmc_traffic.json
-rm -rf gpurun_out/pmc3
-cut -c1-600 $out/bench_n1.json; head -8 $out/kernel_stats_bench.csv | cut -c1-160; tail -9 $out/pmc.log
+# 3. rocprofv3 --stats of the same command (kernel averages must agree with roofline.avg_launch_us)
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-breakdown --no-fp32 --no-h2d > $out/prof_bench.log 2>&1
+cp $(ls $out/stats/*/*kernel_stats.csv | head -1) $out/kernel_stats_bench.csv; rm -rf $out/stats
+# 4. serialized per-(kernel, grid) durations
+bash tools/prof_serial.sh > $out/prof_serial.log 2>&1; cp gpurun_out/prof_serial/by_kernel_grid.json $out/serialized_by_kernel_grid.json
+# 5. HBM traffic per kernel family inside the step (separate --pmc passes)
+bash tools/pmc_bench.sh > $out/pmc.log 2>&1; cp gpurun_out/pmc3/summary.json $out/pmc_traffic.json; rm -rf gpurun_out/pmc3
+# 6. MFMA pipe utilisation of the step's GEMM shapes incl. the connection-layer ones
+bash tools/pmc_mfma.sh > $out/pmc_mfma.log 2>&1; cp gpurun_out/pmc_mfma/summary.json $out/pmc_mfma_util.json
+# 7. timeline of a replayed step
+bash tools/timeline.sh > $out/timeline.txt 2>&1
+# 8. GEMM K-loop study: K slope + ablations + in-kernel clock (diagnostic builds, env-selected)
+( for ab in 0 1 7 2; do GSTVD_GEMM_ABLATE=$ab python3 tools/clock_probe.py 3072; done
+  for ab in 0 1 2 6; do GSTVD_GEMM256_NIU=4 GSTVD_GEMM_ABLATE=$ab python3 tools/kslope.py nt 4096 4096 | sed "s/^/ABLATE=$ab /"; done
+  for st in 0 1 2 4; do GSTVD_GEMM256_NIU=4 GSTVD_GEMM_ST=$st python3 tools/kslope.py nt 4096 4096 | sed "s/^/ST=$st /"; done
+  python3 tools/kslope.py nt 4096 768 64; python3 tools/kslope.py nn 4096 768 64
+  python3 tools/gemm_bench.py all; python3 tools/write_floor.py ) > $out/gemm_study.txt 2>/dev/null
+# 9. host input path next to the replayed step
+( for m in pinned_async pinned pageable; do python3 tools/h2d_probe.py --mode=$m | tail -5; done ) > $out/h2d_probe.txt 2>/dev/null
+# 10. eval / decode side measurements
+python3 tools/eval_decode_bench.py > $out/eval_decode.json 2> /dev/null
+cut -c1-400 $out/bench_n1.json; tail -3 $out/gpu_tests_full.log; head -6 $out/kernel_stats_bench.csv | cut -c1-150
+# 11. the N>1 code path on one GPU (1-rank RCCL group: collectives, graded slices, bf16 payload, graph capture), both row counts
+for rows in 16 10; do GSTVD_FORCE_DIST=1 python3 bench.py --steps 10 --warmup 2 --rows-per-gpu $rows --grad-compress bf16 --no-cpu-baseline --no-breakdown --no-fp32 --no-h2d 2>/dev/null | tail -1 > $out/bench_force_dist_rows$rows.json; done
+python3 bench.py --steps 10 --warmup 2 --rows-per-gpu 10 --no-cpu-baseline --no-fp32 --no-h2d 2>/dev/null | tail -1 > $out/bench_n1_rows10.json
+cut -c1-300 $out/bench_force_dist_rows10.json
