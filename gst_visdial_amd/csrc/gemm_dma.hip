@@ -239,7 +239,9 @@ static int dma_layout(const GemmP& p, int64_t batch, hipStream_t s) {
   if (variant == 3) return dma_launch<OT, 64, 64, 2, 2, AKM, BKM, 4>(p, batch, s);
   // (32x32 / 32x64 tiles for the skinny M = 400 / 592 problems were measured in round 2: no faster -- 400x768x768 9.8-11.0 us
   // against 10.2 us, 592x1024x1024 16.5 us against 13.1 us -- the ring of a workgroup is latency bound, 7 stages x stage
-  // bytes in flight per ~2 us round trip, so halving the tile halves the bytes in flight along with the bytes needed.)
+  // bytes in flight per ~2 us round trip, so halving the tile halves the bytes in flight along with the bytes needed.
+  // 64x32 tiles -- half the weight bytes per workgroup, twice the workgroups: 8.7-8.8 us against 9.1-9.5 us at M = 400, 18 us
+  // against 13 us at M = 592.  Not adopted.)
   return dma_launch<OT, 64, 64, 2, 2, AKM, BKM, 8>(p, batch, s);
 }
 

@@ -136,7 +136,7 @@ DEVFN void dma_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char
     // PF = -1 / -2 / -6 are timing-only ablations (wrong results): -1 = no DMA inside the loop, -2 = no LDS reads / MFMA,
     // -6 = no epilogue
     const bool late = (ST == 1 || ST == 2) && wave >= 4;       // wave-uniform
-    if (ST == 4 && PF != -2) {
+    if ((ST == 4 || ST == 5) && PF != -2) {
       // fragment reads first, all twelve of them (48 VGPRs): the compiler's own schedule reads two A fragments at a time right
       // before the eight MFMAs that use them, which leaves the matrix pipe waiting on LDS latency eight times per step
       // (in-kernel stamps: 1617 cycles per step for 1024 cycles of MFMA work with the DMA switched off).  Then the DMA issue,
@@ -149,18 +149,33 @@ DEVFN void dma_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char
 #pragma unroll
       for (int i = 0; i < MI; ++i) fa[i] = frag32<BM, AKM>(cA, wm * WTM + i * 16, lane);
       __builtin_amdgcn_sched_barrier(0);
+      // ST = 5: reads first AND the second wave of every SIMD (waves 4-7) issues its DMA in the middle / at the end of its MFMAs,
+      // so that one wave of the SIMD starts feeding the matrix pipe as soon as its fragments arrive while the other one spends
+      // its first ~260 cycles issuing DMA
+      const bool late5 = ST == 5 && wave >= 4;
       if (PF == -1) {
         ua.issue(1 << 20, p.K, smem + fill * STAGE, wave);
         ub.issue(1 << 20, p.K, smem + fill * STAGE + A_BYTES, wave);
-      } else {
+      } else if (!late5) {
         ua.issue(t + NS - 1, p.K, smem + fill * STAGE, wave);
         ub.issue(t + NS - 1, p.K, smem + fill * STAGE + A_BYTES, wave);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
+      for (int i = 0; i < MI; ++i) {
+        if (ST == 5 && i == MI / 2) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (late5 && PF != -1) ua.issue(t + NS - 1, p.K, smem + fill * STAGE, wave);
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = mfma_bf16_k32(fb[j], fa[i], acc[i][j]);
+      }
+      if (ST == 5) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (late5 && PF != -1) ub.issue(t + NS - 1, p.K, smem + fill * STAGE + A_BYTES, wave);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       slot = (slot + 1 == NS) ? 0 : slot + 1;
       fill = (fill + 1 == NS) ? 0 : fill + 1;
       continue;
@@ -175,7 +190,13 @@ DEVFN void dma_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char
     }
     const char* cA = smem + slot * STAGE;
     const char* cB = cA + A_BYTES;
-    if (PF != -2) {
+    if (PF == -8) {       // timing-only: real DMA, 32 MFMAs per wave on registers that are never reloaded (no LDS fragment reads)
+      bf16x8 fx = __builtin_bit_cast(bf16x8, (u32x4){(unsigned)lane, 1u, 2u, (unsigned)t});
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = mfma_bf16_k32(fx, fx, acc[i][j]);
+    } else if (PF != -2) {
       bf16x8 fb[NI];
 #pragma unroll
       for (int j = 0; j < NI; ++j) fb[j] = frag32<BN, BKM>(cB, wn * WTN + j * 16, lane);
@@ -390,9 +411,12 @@ static int launch256(const GemmP& p, int64_t batch, int niu, hipStream_t s) {
   auto c1 = gemm_dma256_kernel<OT, AKM, BKM, -1, 4, 3>;
   auto c2 = gemm_dma256_kernel<OT, AKM, BKM, -2, 4, 3>;
   auto c7 = gemm_dma256_kernel<OT, AKM, BKM, -7, 4, 3>;
+  auto c8 = gemm_dma256_kernel<OT, AKM, BKM, -8, 4, 3>;
   auto p0 = gemm_dma256_kernel<OT, AKM, BKM, 0, 4, 4>;
   auto p3 = gemm_dma256_kernel<OT, AKM, BKM, 0, 3, 4>;
   auto p1 = gemm_dma256_kernel<OT, AKM, BKM, -1, 4, 4>;
+  auto q0 = gemm_dma256_kernel<OT, AKM, BKM, 0, 4, 5>;
+  auto q3 = gemm_dma256_kernel<OT, AKM, BKM, 0, 3, 5>;
   auto ka = gemm_dma256_kernel<OT, AKM, BKM, -1>;
   auto kb = gemm_dma256_kernel<OT, AKM, BKM, -2>;
   auto ke = gemm_dma256_kernel<OT, AKM, BKM, -5>;
@@ -400,14 +424,15 @@ static int launch256(const GemmP& p, int64_t batch, int niu, hipStream_t s) {
   static int attr_rc = ensure_lds(k0, LDS256) | ensure_lds(k3, LDS256) | ensure_lds(ka, LDS256) | ensure_lds(kb, LDS256) |
                        ensure_lds(ke, LDS256) | ensure_lds(kf, LDS256) | ensure_lds(s10, LDS256) | ensure_lds(s13, LDS256) |
                        ensure_lds(s20, LDS256) | ensure_lds(s23, LDS256) |
-                       ensure_lds(c0, LDS256) | ensure_lds(c1, LDS256) | ensure_lds(c2, LDS256) | ensure_lds(c7, LDS256) |
-                       ensure_lds(p0, LDS256) | ensure_lds(p3, LDS256) | ensure_lds(p1, LDS256);
+                       ensure_lds(c0, LDS256) | ensure_lds(c1, LDS256) | ensure_lds(c2, LDS256) | ensure_lds(c7, LDS256) | ensure_lds(c8, LDS256) |
+                       ensure_lds(p0, LDS256) | ensure_lds(p3, LDS256) | ensure_lds(p1, LDS256) | ensure_lds(q0, LDS256) |
+                       ensure_lds(q3, LDS256);
   if (attr_rc) return attr_rc;
   static const int abl = [] { const char* e = getenv("GSTVD_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
   static const int st = [] { const char* e = getenv("GSTVD_GEMM_ST"); return e ? atoi(e) : 0; }();
   const int bnu = (niu == 3 && abl == 0) ? 192 : 256;
   const int ntm = (int)((p.M + 255) / 256), ntn = (int)((p.N + bnu - 1) / bnu);
-  GSTVD_LAUNCH(st == 4 ? (abl == 1 ? p1 : bnu == 192 ? p3 : p0) : st == 3 ? (abl == 1 ? c1 : abl == 2 ? c2 : abl == 7 ? c7 : c0) : abl == 1 ? ka : abl == 2 ? kb : abl == 5 ? ke : abl == 6 ? kf :
+  GSTVD_LAUNCH(st == 5 ? (bnu == 192 ? q3 : q0) : st == 4 ? (abl == 1 ? p1 : bnu == 192 ? p3 : p0) : st == 3 ? (abl == 1 ? c1 : abl == 2 ? c2 : abl == 7 ? c7 : abl == 8 ? c8 : c0) : abl == 1 ? ka : abl == 2 ? kb : abl == 5 ? ke : abl == 6 ? kf :
                      st == 1 ? (bnu == 192 ? s13 : s10) : st == 2 ? (bnu == 192 ? s23 : s20) : (bnu == 192 ? k3 : k0),
                      dim3((unsigned)(ntm * ntn), (unsigned)batch), dim3(512), LDS256, s, p, ntn, ntm * ntn);
   GSTVD_LAUNCH_CHECK();
