@@ -280,8 +280,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(gstvd_attn_t a) {
 // backward, part 1: dQ (and delta = rowsum(dO * O)); same tiling as forward
 // =====================================================================================================
 template <typename T, int D>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(gstvd_attn_t a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+DEVFN void attn_bwd_dq_body(const gstvd_attn_t& a, const int bx, char* smem) {
   constexpr bool BF = Img<T, D>::BF;
   char* sKr = smem;                                           // row image of K
   char* sKt = BF ? smem + Img<T, D>::BYTES : smem;            // transposed-read image of K
@@ -289,7 +288,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(gstvd_attn_t a) {
   float* smask = (float*)(smem + (BF ? 3 : 2) * Img<T, D>::BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int q = blockIdx.x * 64 + wave * 16 + li;
+  const int q = bx * 64 + wave * 16 + li;
   const bool qv = q < a.Lq;
   const T* Qb = (const T*)a.Q + (int64_t)b * a.Lq * a.ldq + h * D;
   const T* Kb = (const T*)a.K + (int64_t)b * a.Lk * a.ldk + h * D;
@@ -364,8 +363,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(gstvd_attn_t a) {
 // backward, part 2: dK and dV; one wave owns 16 keys, queries stream through LDS
 // =====================================================================================================
 template <typename T, int D>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(gstvd_attn_t a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+DEVFN void attn_bwd_dkv_body(const gstvd_attn_t& a, const int bx, char* smem) {
   constexpr bool BF = Img<T, D>::BF;
   constexpr int IB = Img<T, D>::BYTES;
   char* sQr = smem;
@@ -376,8 +374,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(gstvd_attn_t a) {
   float* sDel = sLse + 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int key = blockIdx.x * 64 + wave * 16 + li;
+  const int key = bx * 64 + wave * 16 + li;
   const bool kv = key < a.Lk;
+  const T* Ob = (const T*)a.O + (int64_t)b * a.Lq * a.ldo + h * D;
   const T* Qb = (const T*)a.Q + (int64_t)b * a.Lq * a.ldq + h * D;
   const T* Kb = (const T*)a.K + (int64_t)b * a.Lk * a.ldk + h * D;
   const T* Vb = (const T*)a.V + (int64_t)b * a.Lk * a.ldv + h * D;
@@ -395,15 +394,31 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(gstvd_attn_t a) {
 #pragma unroll
   for (int i = 0; i < D / 16; ++i) accK[i] = accV[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // delta[q] = rowsum(dO * O) is recomputed here for every query chunk (four threads per query row, a quarter of the head
+  // dimension each) instead of being read from the dQ half: the two halves of the backward then share no data and run as ONE
+  // launch, side by side (they used to be two dependent launches).
   Stage64<T, D> pq, po;
   float plse = INFINITY, pdel = 0.f;
   auto prefetch = [&](int c0) {
     pq.load(Qb, a.ldq, c0, a.Lq, tid);
     po.load(dOb, a.lddo, c0, a.Lq, tid);
+    const int qq = c0 + (tid >> 2), part = tid & 3;
+    float dsum = 0.f;
+    if (qq < a.Lq) {
+      const T* dr = dOb + (int64_t)qq * a.lddo + part * (D / 4);
+      const T* orow = Ob + (int64_t)qq * a.ldo + part * (D / 4);
+#pragma unroll
+      for (int e = 0; e < D / 4; e += 4) {
+        const f32x4 x = ld4(dr + e), y = ld4(orow + e);
+        dsum += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+      }
+    }
+    dsum += __shfl_xor(dsum, 1, 64);
+    dsum += __shfl_xor(dsum, 2, 64);
+    pdel = dsum;                                              // valid in the lanes with part == 0
     if (tid < 64) {
-      const int qq = c0 + tid;
-      plse = qq < a.Lq ? a.LSE[stat0 + qq] : INFINITY;         // +inf => p = 0 for padded query rows
-      pdel = qq < a.Lq ? a.delta[stat0 + qq] : 0.f;
+      const int q1 = c0 + tid;
+      plse = q1 < a.Lq ? a.LSE[stat0 + q1] : INFINITY;        // +inf => p = 0 for padded query rows
     }
   };
   prefetch(0);
@@ -411,7 +426,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(gstvd_attn_t a) {
     __syncthreads();
     pq.store(sQr, BF ? sQt : nullptr, tid);
     po.store(sOr, BF ? sOt : nullptr, tid);
-    if (tid < 64) { sLse[tid] = plse; sDel[tid] = pdel; }
+    if (tid < 64) sLse[tid] = plse;
+    if ((tid & 3) == 0) sDel[tid >> 2] = pdel;
     __syncthreads();
     if (c0 + 64 < a.Lq) prefetch(c0 + 64);
     const int ntile = (a.Lq - c0 + 15) / 16 < 4 ? (a.Lq - c0 + 15) / 16 : 4;
@@ -476,19 +492,26 @@ template <typename T, int D> static int attn_fwd_launch(const gstvd_attn_t& a, h
   GSTVD_LAUNCH_CHECK();
   return 0;
 }
+// One launch for the whole backward: blocks [0, nkb) own 64 keys each (dK, dV), blocks [nkb, nkb + nqb) own 64 queries each (dQ).
+// The dK/dV blocks come first: they are the longer ones (two second products per tile).
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(gstvd_attn_t a, int nkb) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int bx = blockIdx.x;
+  if (bx < nkb) attn_bwd_dkv_body<T, D>(a, bx, smem);
+  else attn_bwd_dq_body<T, D>(a, bx - nkb, smem);
+}
+
 template <typename T, int D> static int attn_bwd_launch(const gstvd_attn_t& a, hipStream_t s) {
   constexpr bool BF = sizeof(T) == 2;
   constexpr int lds1 = (BF ? 3 : 2) * Img<T, D>::BYTES + 64 * 4;
   constexpr int lds2 = (BF ? 4 : 2) * Img<T, D>::BYTES + 128 * 4;
-  static int rc1 = attn_lds_attr(attn_bwd_dq_kernel<T, D>, lds1);
-  static int rc2 = attn_lds_attr(attn_bwd_dkv_kernel<T, D>, lds2);
-  if (rc1) return rc1;
-  if (rc2) return rc2;
-  dim3 g1((unsigned)((a.Lq + 63) / 64), (unsigned)a.nh, (unsigned)a.B);
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D>), g1, dim3(256), lds1, s, a);
-  GSTVD_LAUNCH_CHECK();
-  dim3 g2((unsigned)((a.Lk + 63) / 64), (unsigned)a.nh, (unsigned)a.B);
-  hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D>), g2, dim3(256), lds2, s, a);
+  constexpr int lds = lds1 > lds2 ? lds1 : lds2;
+  static int rc = attn_lds_attr(attn_bwd_kernel<T, D>, lds);
+  if (rc) return rc;
+  const int nkb = (a.Lk + 63) / 64, nqb = (a.Lq + 63) / 64;
+  dim3 grid((unsigned)(nkb + nqb), (unsigned)a.nh, (unsigned)a.B);
+  hipLaunchKernelGGL((attn_bwd_kernel<T, D>), grid, dim3(256), lds, s, a, nkb);
   GSTVD_LAUNCH_CHECK();
   return 0;
 }
