@@ -189,7 +189,9 @@ extern "C" int gstvd_gemm(const gstvd_gemm_t* g, gstvd_stream_t stream) {
   if (prc) return prc;
   hipStream_t s = (hipStream_t)stream;
   if (g->dtype_in == GSTVD_BF16 && (g->dtype_out == GSTVD_BF16 || g->dtype_out == GSTVD_F32)) {
-    int rc = gemm_dma256_dispatch(p, g->batch, g->a_kmajor, g->b_kmajor, g->dtype_out == GSTVD_F32, s);
+    int rc = gemv16_dispatch(p, g->batch, g->a_kmajor, g->b_kmajor, g->dtype_out == GSTVD_F32, s);     // decode step: M <= 16
+    if (rc != GSTVD_E_UNSUPPORTED) return rc;
+    rc = gemm_dma256_dispatch(p, g->batch, g->a_kmajor, g->b_kmajor, g->dtype_out == GSTVD_F32, s);
     if (rc != GSTVD_E_UNSUPPORTED) return rc;
     rc = gemm_dma_dispatch(p, g->batch, g->a_kmajor, g->b_kmajor, g->dtype_out == GSTVD_F32, s);
     if (rc != GSTVD_E_UNSUPPORTED) return rc;

@@ -911,12 +911,13 @@ class Engine(object):
             st["kv"] = self.lin(enc, "dec.ckv.w", "dec.ckv.b", 2 * L * H, H)      # cross K/V of all layers, once
             Umax = L0 + max_seq_len
             st["Umax"] = Umax
-            st["Kc"] = [Act(self.buf(Bn * Umax, H), Bn * Umax, H) for _ in range(L)]
-            st["Vc"] = [Act(self.buf(Bn * Umax, H), Bn * Umax, H) for _ in range(L)]
+            # per-layer cache of the fused Q|K|V rows, [B, Umax, 3H]: the QKV GEMM of position t writes its output rows straight
+            # into cache[:, t] (row stride Umax*3H), attention reads K / V from the same rows -- no append copies
+            st["QKVc"] = [Act(self.buf(Bn * Umax, 3 * H), Bn * Umax, 3 * H) for _ in range(L)]
             st["mark"] = self.arena.mark()
 
         def one_token(tok, t):
-            I, Bn, S, kv, Kc, Vc, Umax = st["I"], st["Bn"], st["S"], st["kv"], st["Kc"], st["Vc"], st["Umax"]
+            I, Bn, S, kv, QKVc, Umax = st["I"], st["Bn"], st["S"], st["kv"], st["QKVc"], st["Umax"]
             V, Vp = dc.vocab_size, self.flat.Vp
             L, H, nh, eps = dc.num_hidden_layers, dc.hidden_size, dc.num_attention_heads, dc.layer_norm_eps
             d = H // nh
@@ -925,10 +926,11 @@ class Engine(object):
             y = self.embed(prefix, tok.contiguous(), None, Bn, 1, dc, pos_offset=t)
             for i in range(L):
                 p = "d%d" % i
-                qkv = self.lin(y, p + ".qkv.w", p + ".qkv.b", 3 * H, H)
-                Kc[i].t.view(Bn, Umax, H)[:, t].copy_(qkv.t[:, H:2 * H])
-                Vc[i].t.view(Bn, Umax, H)[:, t].copy_(qkv.t[:, 2 * H:])
-                ctx = self.attn((qkv, 0), (Kc[i], 0), (Vc[i], 0), Bn, nh, 1, t + 1, d, None, False, -10000.0, 0.0, kv_bstride=Umax)
+                rows_t = QKVc[i].t.view(Bn, Umax, 3 * H)[:, t]                     # [Bn, 3H] view, row stride Umax * 3H
+                ops.gemm(y.t, self.W[p + ".qkv.w"], rows_t, Bn, 3 * H, H, bias=self.Pv[p + ".qkv.b"])
+                qkv = Act(rows_t, Bn, 3 * H)
+                ctx = self.attn((qkv, 0), (QKVc[i], H), (QKVc[i], 2 * H), Bn, nh, 1, t + 1, d, None, False, -10000.0, 0.0,
+                                kv_bstride=Umax)
                 ao = self.lin(ctx, p + ".ao.w", p + ".ao.b", H, H)
                 y1 = self.ln(ao, y, p + ".ln1.w", p + ".ln1.b", H, 0.0, None, eps)
                 q = self.lin(y1, p + ".cq.w", p + ".cq.b", H, H)

@@ -172,6 +172,8 @@ def splitk_plan(dtype_in, M, N, K, batch, a_km, b_km):
     most of the 256 CUs idle and each split must still run a ring's worth of K-tiles."""
     if not SPLITK or dtype_in != BF16 or batch != 1 or (a_km and not b_km):
         return 1
+    if M <= 16 and not a_km and not b_km:
+        return 1                                    # the skinny kernel of csrc/gemv.hip takes it (one launch, K split over waves)
     if M >= 256 and N >= 128 and ((M + 127) // 128) * ((N + 127) // 128) >= 96:
         return 1                                    # the 128 / 256 tile kernels take it
     tiles = ((M + 63) // 64) * ((N + 63) // 64)

@@ -497,3 +497,39 @@ def test_gemm_randomised_regression():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.run(120, seed=11, verbose=False) == 0
+
+
+@pytest.mark.parametrize("M,N,K", [(16, 768, 768), (16, 3072, 768), (16, 768, 3072), (3, 2304, 768), (1, 136, 200), (16, 30528, 768),
+                                   (7, 64, 40)])
+@pytest.mark.parametrize("out", [torch.bfloat16, torch.float32])
+def test_skinny_decode_gemm(M, N, K, out):
+    """csrc/gemv.hip: the M <= 16 shape of a KV-cached decode step (one new token per row): bias / residual add / GELU (+ gelu'),
+    strided output rows (written straight into a cache row), tails in N and K, bf16 and fp32 outputs; and the library really
+    dispatches this shape to the skinny kernel."""
+    import ctypes as C
+    o = ops()
+    x, w, b = rnd(M, K, dtype=torch.bfloat16, seed=40), rnd(N, K, dtype=torch.bfloat16, seed=41, s=0.1), rnd(N, seed=42)
+    ref = x.float() @ w.float().t() + b
+    big = torch.zeros(M, 3, N, device=DEV, dtype=out)               # output rows with a stride of 3N (row t = 1 of a [M, 3, N] cache)
+    y = big[:, 1]
+    o.gemm(x, w, y, M, N, K, bias=b)
+    check("skinny_bias", y.contiguous(), ref, torch.bfloat16)
+    assert float(big[:, 0].abs().max()) == 0.0 and float(big[:, 2].abs().max()) == 0.0
+    if out == torch.bfloat16:
+        r = rnd(M, N, dtype=torch.bfloat16, seed=43)
+        y2 = torch.empty(M, N, device=DEV, dtype=out)
+        o.gemm(x, w, y2, M, N, K, bias=b, addend=r)
+        check("skinny_add", y2, ref + r.float(), torch.bfloat16)
+        u = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        a = torch.empty(M, N, device=DEV, dtype=out)
+        o.gemm(x, w, a, M, N, K, bias=b, aux=u, epi=o.EPI_GELU)
+        uref = ref.clone().requires_grad_(True)
+        aref = torch.nn.functional.gelu(uref)
+        aref.backward(torch.ones_like(aref))
+        check("skinny_gelu", a, aref.detach(), torch.bfloat16)
+        check("skinny_gelu_deriv", u, uref.grad, torch.bfloat16)
+    from gst_visdial_amd import _lib as L
+    d = L.GemmDesc()
+    d.A, d.B, d.C, d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.batch = x.data_ptr(), w.data_ptr(), y.data_ptr(), M, N, K, K, K, 3 * N, 1
+    d.dtype_in, d.dtype_out, d.alpha = L.BF16, (L.BF16 if out == torch.bfloat16 else L.F32), 1.0
+    assert "gemv16_kernel" in o.gemm_kernel_symbol(d)
