@@ -85,7 +85,8 @@ struct Dma32 {
 // 256-wide LDS image -- N = 3072 then gives 16 x 16 = 256 tiles, one per CU, instead of 192 tiles on 256 CUs).
 // ST = stagger of the LDS-DMA issue inside a K-step.  All eight waves used to run the same sequence -- wait, barrier, issue
 // their 4 DMA pieces (~100+ cycles of issue each), read fragments, 32 MFMAs -- so both waves of a SIMD sat in the DMA-issue
-// phase together and the matrix pipe idled meanwhile (0.95 us per step against 0.43 us of MFMA work).  ST = 1: waves 0-3
+// phase together and the matrix pipe idled meanwhile (0.95 us per step against 0.43 us of MFMA work).  (ST = 1 / 2 / 5 were
+// measured in round 2 -- no gain, see DESIGN.md section 5 -- and are no longer instantiated; the code stays for the record.)  ST = 1: waves 0-3
 // (first wave of every SIMD) issue early as before, waves 4-7 issue their A pieces after half of their MFMAs and their B pieces
 // after the rest: one wave of a SIMD feeds the matrix pipe while its partner talks to the memory pipeline.  ST = 2: the late
 // half issues everything after its MFMAs.  The ring accounting is unchanged (a wave still issues LPS pieces per step, the
@@ -403,10 +404,6 @@ template <typename OT, bool AKM, bool BKM>
 static int launch256(const GemmP& p, int64_t batch, int niu, hipStream_t s) {
   auto k0 = gemm_dma256_kernel<OT, AKM, BKM, 0>;
   auto k3 = gemm_dma256_kernel<OT, AKM, BKM, 0, 3>;
-  auto s10 = gemm_dma256_kernel<OT, AKM, BKM, 0, 4, 1>;
-  auto s13 = gemm_dma256_kernel<OT, AKM, BKM, 0, 3, 1>;
-  auto s20 = gemm_dma256_kernel<OT, AKM, BKM, 0, 4, 2>;
-  auto s23 = gemm_dma256_kernel<OT, AKM, BKM, 0, 3, 2>;
   auto c0 = gemm_dma256_kernel<OT, AKM, BKM, 0, 4, 3>;
   auto c1 = gemm_dma256_kernel<OT, AKM, BKM, -1, 4, 3>;
   auto c2 = gemm_dma256_kernel<OT, AKM, BKM, -2, 4, 3>;
@@ -415,25 +412,22 @@ static int launch256(const GemmP& p, int64_t batch, int niu, hipStream_t s) {
   auto p0 = gemm_dma256_kernel<OT, AKM, BKM, 0, 4, 4>;
   auto p3 = gemm_dma256_kernel<OT, AKM, BKM, 0, 3, 4>;
   auto p1 = gemm_dma256_kernel<OT, AKM, BKM, -1, 4, 4>;
-  auto q0 = gemm_dma256_kernel<OT, AKM, BKM, 0, 4, 5>;
-  auto q3 = gemm_dma256_kernel<OT, AKM, BKM, 0, 3, 5>;
+
   auto ka = gemm_dma256_kernel<OT, AKM, BKM, -1>;
   auto kb = gemm_dma256_kernel<OT, AKM, BKM, -2>;
   auto ke = gemm_dma256_kernel<OT, AKM, BKM, -5>;
   auto kf = gemm_dma256_kernel<OT, AKM, BKM, -6>;
   static int attr_rc = ensure_lds(k0, LDS256) | ensure_lds(k3, LDS256) | ensure_lds(ka, LDS256) | ensure_lds(kb, LDS256) |
-                       ensure_lds(ke, LDS256) | ensure_lds(kf, LDS256) | ensure_lds(s10, LDS256) | ensure_lds(s13, LDS256) |
-                       ensure_lds(s20, LDS256) | ensure_lds(s23, LDS256) |
+                       ensure_lds(ke, LDS256) | ensure_lds(kf, LDS256) | 
                        ensure_lds(c0, LDS256) | ensure_lds(c1, LDS256) | ensure_lds(c2, LDS256) | ensure_lds(c7, LDS256) | ensure_lds(c8, LDS256) |
-                       ensure_lds(p0, LDS256) | ensure_lds(p3, LDS256) | ensure_lds(p1, LDS256) | ensure_lds(q0, LDS256) |
-                       ensure_lds(q3, LDS256);
+                       ensure_lds(p0, LDS256) | ensure_lds(p3, LDS256) | ensure_lds(p1, LDS256);
   if (attr_rc) return attr_rc;
   static const int abl = [] { const char* e = getenv("GSTVD_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
   static const int st = [] { const char* e = getenv("GSTVD_GEMM_ST"); return e ? atoi(e) : 0; }();
   const int bnu = (niu == 3 && abl == 0) ? 192 : 256;
   const int ntm = (int)((p.M + 255) / 256), ntn = (int)((p.N + bnu - 1) / bnu);
-  GSTVD_LAUNCH(st == 5 ? (bnu == 192 ? q3 : q0) : st == 4 ? (abl == 1 ? p1 : bnu == 192 ? p3 : p0) : st == 3 ? (abl == 1 ? c1 : abl == 2 ? c2 : abl == 7 ? c7 : abl == 8 ? c8 : c0) : abl == 1 ? ka : abl == 2 ? kb : abl == 5 ? ke : abl == 6 ? kf :
-                     st == 1 ? (bnu == 192 ? s13 : s10) : st == 2 ? (bnu == 192 ? s23 : s20) : (bnu == 192 ? k3 : k0),
+  GSTVD_LAUNCH(st == 4 ? (abl == 1 ? p1 : bnu == 192 ? p3 : p0) : st == 3 ? (abl == 1 ? c1 : abl == 2 ? c2 : abl == 7 ? c7 : abl == 8 ? c8 : c0) : abl == 1 ? ka : abl == 2 ? kb : abl == 5 ? ke : abl == 6 ? kf :
+                     (bnu == 192 ? k3 : k0),
                      dim3((unsigned)(ntm * ntn), (unsigned)batch), dim3(512), LDS256, s, p, ntn, ntm * ntn);
   GSTVD_LAUNCH_CHECK();
   return 0;
@@ -472,15 +466,13 @@ int gemm_dma256_dispatch(const GemmP& p, int64_t batch, int akm, int bkm, int ou
 template <typename OT, bool AKM, bool BKM>
 static int grouped256(const gstvd_gemm_t* tab, const int* off, int nprob, int total, hipStream_t s) {
   auto k0 = gemm_dma256_grouped_kernel<OT, AKM, BKM, 0>;
-  auto k1 = gemm_dma256_grouped_kernel<OT, AKM, BKM, 0, 1>;
-  auto k2 = gemm_dma256_grouped_kernel<OT, AKM, BKM, 0, 2>;
   auto k4 = gemm_dma256_grouped_kernel<OT, AKM, BKM, 0, 4>;
-  static int attr_rc = ensure_lds(k0, LDS256) | ensure_lds(k1, LDS256) | ensure_lds(k2, LDS256) | ensure_lds(k4, LDS256);
+  static int attr_rc = ensure_lds(k0, LDS256) | ensure_lds(k4, LDS256);
   if (attr_rc) return attr_rc;
   static const int st = [] { const char* e = getenv("GSTVD_GEMM_ST"); return e ? atoi(e) : 0; }();
   // tiles per XCD chunk = 2^chs (default 8: measured best of 1..128 inside the step); GSTVD_GROUP_CHUNK_LOG2 overrides for tuning runs
   static const int chs = [] { const char* e = getenv("GSTVD_GROUP_CHUNK_LOG2"); const int v = e ? atoi(e) : 3; return v < 0 ? 0 : (v > 10 ? 10 : v); }();
-  GSTVD_LAUNCH(st == 1 ? k1 : st == 2 ? k2 : st == 4 ? k4 : k0, dim3((unsigned)total), dim3(512), LDS256, s, tab, off, nprob, total, chs);
+  GSTVD_LAUNCH(st == 4 ? k4 : k0, dim3((unsigned)total), dim3(512), LDS256, s, tab, off, nprob, total, chs);
   GSTVD_LAUNCH_CHECK();
   return 0;
 }
