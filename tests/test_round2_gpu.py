@@ -355,3 +355,50 @@ def test_pinned_double_buffered_staging_and_prefetch():
         assert got == plain, mode
     assert torch.get_num_threads() >= 1
     assert len(set(plain)) == 5                    # the batches really differ
+
+
+@pytest.mark.isolated
+def test_graph_replay_follows_the_learning_rate_schedule():
+    """host-side schedule work must stay OUTSIDE the captured function.  The documented pattern -- replay the
+    captured device step, then `scheduler_step()` + `upload_lr()` on the host -- applies a different learning rate every step
+    (warm-up ramp, then decay) exactly like the eager loop; capturing the scheduler call inside the step would freeze it."""
+    from gst_visdial_amd.optim import FusedAdamW
+    from gst_visdial_amd.graph import GraphedStep
+    s = sc()
+    g = load_npz("tiny_train.npz")
+
+    def run(graphed, n=7):
+        model, params, cfg = s.build_tiny_model("fp32", DEV, seed=9)
+        model.eval()
+        kw = s.golden_batch(g, DEV)
+        opt = FusedAdamW(model, lr=5e-3, warmup_steps=3, t_total=12, min_lr=1e-5)
+        lrs = []
+
+        def device_step():
+            loss, _ = model(**kw)
+            loss.backward()
+            opt.step()
+            opt.zero_grad()
+            return loss
+
+        def host_end():
+            lrs.append(opt.current_lrs()[0])
+            opt.scheduler_step()
+            opt.upload_lr()
+
+        if graphed:
+            for _ in range(2):
+                device_step(); host_end()
+            step = GraphedStep(device_step, warmup=0)
+            for _ in range(n - 2):
+                step(); host_end()
+        else:
+            for _ in range(n):
+                device_step(); host_end()
+        torch.cuda.synchronize()
+        return lrs, model.engine.flat.P.clone()
+
+    lr_e, p_e = run(False)
+    lr_g, p_g = run(True)
+    assert lr_e == lr_g and len(set(lr_e)) >= 5                      # the schedule really moves from step to step
+    assert maxerr(p_e, p_g) < 1e-6
