@@ -767,6 +767,7 @@ class Engine(object):
 
     def _begin(self, device, record):
         self.prepare(device)
+        self._last_decode = None          # the arena is rewound: a previous decode call's encoder states are about to be overwritten
         self.arena.reset()
         self.tape, self.rec = [], record
         self.tag = "t"
@@ -1023,7 +1024,6 @@ class Engine(object):
         self.last = dict(decode_logits=logits)            # last position's raw logits (tests / debugging)
         # the encoder side of this call (cross-attention K/V of all layers, masks) stays valid in the arena until the next
         # engine call: `rescore_sampled` scores the sampled answer against it without a second encoder pass
-        self._last_decode = (dst, ids.shape[0], self.arena)
         out = decoding.pad_after_eos(torch.cat(seq, 1), dc.eos_token_id, dc.pad_token_id)
         if use_graph and sess is None:
             # first call with these shapes ran eagerly (it also initialised every lazily built table / attribute / arena
@@ -1031,6 +1031,9 @@ class Engine(object):
             if len(self._decode_sessions) >= 4:
                 self._decode_sessions.clear()
             self._decode_sessions[sig] = self._decode_session(ins, L0, max_seq_len)
+        # (after the capture: capturing runs the Python side of encode() again -- which rewinds the arena bookkeeping and drops
+        # this marker -- but executes nothing, so the eager call's encoder states are still what the arena holds)
+        self._last_decode = (dst, ids.shape[0], self.arena)
         return out
 
 
