@@ -365,6 +365,107 @@ DEVFN void pp_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char*
       gemm_epilogue_tile<bf16, OT>(p, dk, acc[i][j], z, m0 + wm * WTM + i * 16 + li, n0 + wn * WTN + j * 16 + 4 * g);
 }
 
+// Producer / consumer form of the same tile (GSTVD_GEMM_PC=1): 12 waves.  Waves 0-7 are the MFMA consumers of dma_tile256 (128x64 each)
+// and never touch the memory pipeline; waves 8-11 are LDS-DMA producers (8 pieces of 1 KB per wave and stage) and never touch
+// the matrix pipe.  One s_barrier per K-step still orders everything: before barrier t every producer has waited for its pieces
+// of stage t (counted vmcnt) and every consumer has retired its fragment reads of slot t-1, so after it the consumers read slot t
+// and the producers refill slot t-1 with stage t+NS-1.  Why: in the 8-wave kernel every wave spends ~260 cycles of each K-step
+// issuing DMA and both waves of a SIMD do so at the same time (section 5 of DESIGN.md: 1358 cycles per step without any DMA
+// instruction, 1725 with); here the consumers' step IS that DMA-free loop and the DMA issue runs beside it on a third wave of
+// the SIMD.  Needs <= 168 VGPRs (three waves per SIMD).
+template <typename OT, bool AKM, bool BKM, int NIU = 4>
+DEVFN void pc_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char* smem) {
+  constexpr int BM = 256, BN = 256, WN = 4, NS = NS256, NTP = 256;
+  constexpr int WTM = 128, WTN = NIU * 16, MI = 8, NI = NIU, BNU = WN * WTN;
+  constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;
+  constexpr int NPA = A_BYTES / (NTP * 16), NPB = B_BYTES / (NTP * 16), LPS = NPA + NPB;      // 4 + 4 pieces per producer wave
+  static_assert((NS - 2) * LPS <= 63, "vmcnt immediate out of range");
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave >= 8;
+  const int ntm = nwg / ntn;
+  const int SWD = g_strip_w;
+  const int strip = wg / (SWD * ntm), sw = (ntn - strip * SWD) < SWD ? (ntn - strip * SWD) : SWD;
+  const int within = wg - strip * SWD * ntm;
+  const int64_t m0 = (int64_t)(within / sw) * BM, n0 = (int64_t)(strip * SWD + within % sw) * BNU;
+  const int64_t nkt = (p.K + 31) / 32;
+
+  if (producer) {
+    const int ptid = tid - 512, pw = wave - 8;
+    Dma32<BM, AKM, NPA, NTP> ua;
+    Dma32<BN, BKM, NPB, NTP> ub;
+    ua.init(p.A + z * p.sA * 2, p.lda, m0, p.M, ptid);
+    ub.init(p.B + z * p.sB * 2, p.ldb, n0, (n0 + BNU < p.N) ? n0 + BNU : p.N, ptid);
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) {
+      ua.issue(s, p.K, smem + s * STAGE, pw);
+      ub.issue(s, p.K, smem + s * STAGE + A_BYTES, pw);
+    }
+    int fill = NS - 1;
+    for (int64_t t = 0; t < nkt; ++t) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPS) : "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      ua.issue(t + NS - 1, p.K, smem + fill * STAGE, pw);
+      ub.issue(t + NS - 1, p.K, smem + fill * STAGE + A_BYTES, pw);
+      fill = (fill + 1 == NS) ? 0 : fill + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the ring's trailing (zero page) pieces
+    __builtin_amdgcn_s_barrier();                          // pairs with the consumers' barrier in front of the epilogue
+    return;
+  }
+
+  const int wm = wave / WN, wn = wave % WN;
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int slot = 0;
+  for (int64_t t = 0; t < nkt; ++t) {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const char* cA = smem + slot * STAGE;
+    const char* cB = cA + A_BYTES;
+    bf16x8 fb[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) fb[j] = frag32<BN, BKM>(cB, wn * WTN + j * 16, lane);
+    if constexpr (NIU <= 3) {          // 96 accumulator registers: room for all eight A fragments up front (no spill at 168 VGPRs)
+      bf16x8 fa[MI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fa[i] = frag32<BM, AKM>(cA, wm * WTM + i * 16, lane);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = mfma_bf16_k32(fb[j], fa[i], acc[i][j]);
+    } else {                           // 128 accumulator registers: A fragments two at a time, like dma_tile256
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const bf16x8 fa = frag32<BM, AKM>(cA, wm * WTM + i * 16, lane);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = mfma_bf16_k32(fb[j], fa, acc[i][j]);
+      }
+    }
+    slot = (slot + 1 == NS) ? 0 : slot + 1;
+  }
+  __builtin_amdgcn_s_barrier();       // every producer has drained its DMAs, every consumer is done with the ring: LDS is free
+  const int g = lane >> 4, li = lane & 15;
+  const DropKey dk = make_drop((p.epi & GSTVD_EPI_DROPOUT) ? p.p : 0.f, p.site, p.rng);
+  if constexpr (sizeof(OT) == 2) {
+    if (epilogue_rows_ok(p)) {
+      gemm_epilogue_rows<MI, NI, 4>(p, dk, acc, z, m0 + wm * WTM, n0 + wn * WTN, smem + wave * epi_wave_bytes<NI, 4>(), lane);
+      return;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+      gemm_epilogue_tile<bf16, OT>(p, dk, acc[i][j], z, m0 + wm * WTM + i * 16 + li, n0 + wn * WTN + j * 16 + 4 * g);
+}
+
 DEVFN int xcd_remap256(int bid, int nwg) {
   const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
@@ -375,6 +476,12 @@ __global__ __launch_bounds__(512) void gemm_dma256_kernel(GemmP p, int ntn, int 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (PF == -5) pp_tile256<OT, AKM, BKM>(p, blockIdx.y, xcd_remap256(blockIdx.x, nwg), ntn, nwg, smem);
   else dma_tile256<OT, AKM, BKM, PF, NIU, ST>(p, blockIdx.y, xcd_remap256(blockIdx.x, nwg), ntn, nwg, smem);
+}
+
+template <typename OT, bool AKM, bool BKM, int NIU = 4>
+__global__ __launch_bounds__(768) void gemm_pc256_kernel(GemmP p, int ntn, int nwg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  pc_tile256<OT, AKM, BKM, NIU>(p, blockIdx.y, xcd_remap256(blockIdx.x, nwg), ntn, nwg, smem);
 }
 
 template <typename OT, bool AKM, bool BKM, int PF, int ST = 0>
@@ -426,6 +533,18 @@ static int launch256(const GemmP& p, int64_t batch, int niu, hipStream_t s) {
   static const int st = [] { const char* e = getenv("GSTVD_GEMM_ST"); return e ? atoi(e) : 0; }();
   const int bnu = (niu == 3 && abl == 0) ? 192 : 256;
   const int ntm = (int)((p.M + 255) / 256), ntn = (int)((p.N + bnu - 1) / bnu);
+  // producer / consumer form: measured -7 % per launch on single-round grids (4096x3072x768 33.8 -> 31.3 us, per K-step 0.82 ->
+  // 0.76 us), +7 % on the 1368-tile cross-K/V projection (its extra ~1.5 us of fixed cost is paid 5.3 times): up to 2 rounds of tiles
+  static const int pc = [] { const char* e = getenv("GSTVD_GEMM_PC"); return e ? atoi(e) : 1; }();
+  if (pc && abl == 0 && st == 0 && (pc == 2 || (int64_t)ntm * ntn * batch <= 512)) {
+    auto c4 = gemm_pc256_kernel<OT, AKM, BKM, 4>;
+    auto c3 = gemm_pc256_kernel<OT, AKM, BKM, 3>;
+    static int pc_rc = ensure_lds(c4, LDS256) | ensure_lds(c3, LDS256);
+    if (pc_rc) return pc_rc;
+    GSTVD_LAUNCH(bnu == 192 ? c3 : c4, dim3((unsigned)(ntm * ntn), (unsigned)batch), dim3(768), LDS256, s, p, ntn, ntm * ntn);
+    GSTVD_LAUNCH_CHECK();
+    return 0;
+  }
   GSTVD_LAUNCH(st == 4 ? (abl == 1 ? p1 : bnu == 192 ? p3 : p0) : st == 3 ? (abl == 1 ? c1 : abl == 2 ? c2 : abl == 7 ? c7 : abl == 8 ? c8 : c0) : abl == 1 ? ka : abl == 2 ? kb : abl == 5 ? ke : abl == 6 ? kf :
                      (bnu == 192 ? k3 : k0),
                      dim3((unsigned)(ntm * ntn), (unsigned)batch), dim3(512), LDS256, s, p, ntn, ntm * ntn);
@@ -464,6 +583,25 @@ int gemm_dma256_dispatch(const GemmP& p, int64_t batch, int akm, int bkm, int ou
 }
 
 template <typename OT, bool AKM, bool BKM>
+__global__ __launch_bounds__(768) void gemm_pc256_grouped_kernel(const gstvd_gemm_t* tab, const int* tile_off, int nprob, int total, int chs) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int full = total - total % (8 << chs), bid = blockIdx.x;
+  const int gid = bid < full ? (((bid >> 3) >> chs) * 8 + (bid & 7)) * (1 << chs) + ((bid >> 3) & ((1 << chs) - 1)) : bid;
+  int lo = 0, hi = nprob - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tile_off[mid] <= gid) lo = mid; else hi = mid - 1; }
+  const gstvd_gemm_t& g = tab[lo];
+  GemmP p;
+  p.A = (const char*)g.A; p.B = (const char*)g.B; p.C = (char*)g.C;
+  p.bias = g.bias; p.addend = (const char*)g.addend; p.aux = (char*)g.aux;
+  p.M = g.M; p.N = g.N; p.K = g.K;
+  p.lda = g.lda; p.ldb = g.ldb; p.ldc = g.ldc; p.ldadd = g.ldadd; p.ldaux = g.ldaux;
+  p.sA = p.sB = p.sC = p.sAdd = p.sAux = 0;
+  p.epi = g.epilogue; p.alpha = g.alpha; p.p = g.dropout_p; p.site = g.site; p.rng = g.rng;
+  const int ntn = (int)((g.N + 255) / 256), ntm = (int)((g.M + 255) / 256);
+  pc_tile256<OT, AKM, BKM, 4>(p, 0, gid - tile_off[lo], ntn, ntm * ntn, smem);
+}
+
+template <typename OT, bool AKM, bool BKM>
 static int grouped256(const gstvd_gemm_t* tab, const int* off, int nprob, int total, hipStream_t s) {
   auto k0 = gemm_dma256_grouped_kernel<OT, AKM, BKM, 0>;
   auto k4 = gemm_dma256_grouped_kernel<OT, AKM, BKM, 0, 4>;
@@ -472,6 +610,17 @@ static int grouped256(const gstvd_gemm_t* tab, const int* off, int nprob, int to
   static const int st = [] { const char* e = getenv("GSTVD_GEMM_ST"); return e ? atoi(e) : 0; }();
   // tiles per XCD chunk = 2^chs (default 8: measured best of 1..128 inside the step); GSTVD_GROUP_CHUNK_LOG2 overrides for tuning runs
   static const int chs = [] { const char* e = getenv("GSTVD_GROUP_CHUNK_LOG2"); const int v = e ? atoi(e) : 3; return v < 0 ? 0 : (v > 10 ? 10 : v); }();
+  // weight gradients are long-K problems (K = rows of the batch): the producer / consumer tile gains ~0.08 us on every one of
+  // their ~128 K-steps (18432x768x4688: 160 -> 143 us)
+  static const int pc = [] { const char* e = getenv("GSTVD_GEMM_PC"); return e ? atoi(e) : 1; }();
+  if (pc && st == 0) {
+    auto kp = gemm_pc256_grouped_kernel<OT, AKM, BKM>;
+    static int pc_rc = ensure_lds(kp, LDS256);
+    if (pc_rc) return pc_rc;
+    GSTVD_LAUNCH(kp, dim3((unsigned)total), dim3(768), LDS256, s, tab, off, nprob, total, chs);
+    GSTVD_LAUNCH_CHECK();
+    return 0;
+  }
   GSTVD_LAUNCH(st == 4 ? k4 : k0, dim3((unsigned)total), dim3(512), LDS256, s, tab, off, nprob, total, chs);
   GSTVD_LAUNCH_CHECK();
   return 0;
