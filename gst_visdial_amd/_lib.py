@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgstvd_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 F32, BF16 = 0, 1
 EPI_BIAS, EPI_ADD, EPI_GELU, EPI_DGELU, EPI_DROPOUT = 1, 2, 4, 8, 16
@@ -41,7 +41,7 @@ class LnDesc(C.Structure):
 class LnBwdDesc(C.Structure):
     _fields_ = [("f", LnDesc), ("dy", _vp), ("lddy", _i64), ("dres", _vp), ("lddres", _i64),
                 ("dx", _vp), ("lddx", _i64), ("partial", _vp),
-                ("dword", _vp), ("dpos", _vp), ("dtt", _vp), ("dtt_ext", _vp)]
+                ("dword", _vp), ("dpos", _vp), ("dtt", _vp), ("dtt_ext", _vp), ("nblk", _i64)]
 
 
 class AttnDesc(C.Structure):
@@ -77,6 +77,7 @@ SIGNATURES = {
     "gstvd_gemm_grouped": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp]),
     "gstvd_ln_fwd": (_i32, [C.POINTER(LnDesc), _vp]),
     "gstvd_ln_bwd_blocks": (_i64, [_i64]),
+    "gstvd_ln_bwd_blocks_for": (_i64, [_i64, _i64, _i32]),
     "gstvd_ln_bwd": (_i32, [C.POINTER(LnBwdDesc), _vp]),
     "gstvd_colsum_partials": (_i32, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _i32, _vp]),
     "gstvd_colsum_batched": (_i32, [_vp, _i64, _i64, _vp]),

@@ -10,11 +10,17 @@ struct LnP {
   // backward extras
   const void* dy; int64_t lddy; void* dres; int64_t lddres; void* dx; int64_t lddx; float* partial;
   float *dword, *dpos, *dtt, *dtt_ext;
+  int64_t nblk_wide;       // > 0: the caller sized `partial` for the 16-wave geometry
 };
 
 // rows per wave in backward: 2 (both rows' loads in flight before any reduction) for large M; 1 for small M, where the
 // grid cannot fill the chip anyway and the shorter per-wave chain is what counts (decoder / vision rows)
 static inline int ln_bwd_rw(int64_t M) { return M <= 8192 ? 1 : 2; }
+// waves per block in backward.  Every block writes one [3][H] slab of column partials; with 4 one-row waves per block that
+// was 9.4 MB of partials for a 4096x768 LayerNorm -- more than any one of its operands -- read again by the column-sum launch
+// (0.34 ms per step).  From 2048 rows up a block has 16 waves (one block per CU, 147 KB of LDS for the per-wave slabs, same
+// number of rows in flight on the chip): a quarter of the partial bytes.  The LayerNorm kernel itself takes the same time.
+static inline int ln_bwd_nw(int64_t M, int mode, int64_t H) { return (M >= 2048 && mode != GSTVD_LN_EMBED && H <= 768) ? 16 : 4; }
 
 // h = pre-LayerNorm row, 4 elements starting at column c
 template <typename T, int MODE>
@@ -99,11 +105,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(gstvd_ln_t f) {
 // at 4096x768 and 13.4 -> 8.0 us at 400x768; RW = 2 beyond).  With RW = 2 both rows' loads are issued
 // before any reduction (memory-level parallelism), column partial sums stay in registers and are combined
 // across the 4 waves through LDS with plain stores (no LDS atomics), one [3][H] slab per block goes to HBM.
-template <typename T, int MODE, int NV, int RW>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(LnP p) {
-  constexpr int LN_BWD_RPB = 4 * RW;
+template <typename T, int MODE, int NV, int RW, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(LnP p) {
+  constexpr int LN_BWD_RPB = NW * RW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* red = (float*)smem;                   // [4 waves][3][H]
+  float* red = (float*)smem;                   // [NW waves][3][H]
   const gstvd_ln_t& f = p.f;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int H = (int)f.H;
@@ -204,9 +210,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnP p) {
   }
   __syncthreads();
   float* out = p.partial + (int64_t)blockIdx.x * NVP * H;
-  for (int i = threadIdx.x * 4; i < NVP * H; i += 1024) {
-    f32x4 a = *(const f32x4*)(red + i) + *(const f32x4*)(red + NVP * H + i) + *(const f32x4*)(red + 2 * NVP * H + i) +
-              *(const f32x4*)(red + 3 * NVP * H + i);
+  for (int i = threadIdx.x * 4; i < NVP * H; i += NW * 256) {
+    f32x4 a = *(const f32x4*)(red + i);
+#pragma unroll
+    for (int w = 1; w < NW; ++w) a += *(const f32x4*)(red + w * NVP * H + i);
     *(f32x4*)(out + i) = a;
   }
 }
@@ -379,6 +386,24 @@ extern "C" int gstvd_ln_fwd(const gstvd_ln_t* p, gstvd_stream_t stream) {
 }
 
 extern "C" int64_t gstvd_ln_bwd_blocks(int64_t M) { const int rpb = 4 * ln_bwd_rw(M); return (M + rpb - 1) / rpb; }
+extern "C" int64_t gstvd_ln_bwd_blocks_for(int64_t M, int64_t H, int32_t mode) {
+  if (ln_bwd_nw(M, mode, H) == 16 && ln_bwd_rw(M) == 1) return (M + 15) / 16;
+  return gstvd_ln_bwd_blocks(M);
+}
+
+template <typename T, int MODE>
+static int ln_bwd_wide(const LnP& p, hipStream_t s) {       // 16 one-row waves per block, H <= 768
+  constexpr int NW = 16;
+  const size_t lds = (size_t)NW * 3 * p.f.H * sizeof(float);
+  static int rc1 = (int)hipFuncSetAttribute((const void*)ln_bwd_kernel<T, MODE, 1, 1, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, NW * 3 * 256 * 4);
+  static int rc3 = (int)hipFuncSetAttribute((const void*)ln_bwd_kernel<T, MODE, 3, 1, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, NW * 3 * 768 * 4);
+  if (rc1 | rc3) return rc1 | rc3;
+  dim3 grid((unsigned)((p.f.M + NW - 1) / NW)), block(NW * 64);
+  if (p.f.H <= 256) hipLaunchKernelGGL((ln_bwd_kernel<T, MODE, 1, 1, NW>), grid, block, lds, s, p);
+  else hipLaunchKernelGGL((ln_bwd_kernel<T, MODE, 3, 1, NW>), grid, block, lds, s, p);
+  GSTVD_LAUNCH_CHECK();
+  return 0;
+}
 
 template <typename T, int MODE, int RW>
 static int ln_bwd_nv(const LnP& p, hipStream_t s) {
@@ -397,6 +422,9 @@ static int ln_bwd_nv(const LnP& p, hipStream_t s) {
 }
 template <typename T, int MODE>
 static int ln_bwd_rows(const LnP& p, hipStream_t s) {
+  if constexpr (MODE != GSTVD_LN_EMBED) {
+    if (p.nblk_wide > 0) return ln_bwd_wide<T, MODE>(p, s);
+  }
   return ln_bwd_rw(p.f.M) == 1 ? ln_bwd_nv<T, MODE, 1>(p, s) : ln_bwd_nv<T, MODE, 2>(p, s);
 }
 template <typename T>
@@ -416,6 +444,9 @@ extern "C" int gstvd_ln_bwd(const gstvd_ln_bwd_t* b, gstvd_stream_t stream) {
   p.f = b->f; p.dy = b->dy; p.lddy = b->lddy; p.dres = b->dres; p.lddres = b->lddres;
   p.dx = b->dx; p.lddx = b->lddx; p.partial = b->partial;
   p.dword = b->dword; p.dpos = b->dpos; p.dtt = b->dtt; p.dtt_ext = b->dtt_ext;
+  const int64_t wide = gstvd_ln_bwd_blocks_for(b->f.M, b->f.H, b->f.mode);
+  p.nblk_wide = (b->nblk > 0 && b->nblk == wide && wide != gstvd_ln_bwd_blocks(b->f.M)) ? wide : 0;
+  if (b->nblk > 0 && b->nblk != wide && b->nblk != gstvd_ln_bwd_blocks(b->f.M)) return GSTVD_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   return b->f.dtype == GSTVD_BF16 ? ln_bwd_mode<bf16>(p, s) : ln_bwd_mode<float>(p, s);
 }

@@ -511,14 +511,14 @@ class Engine(object):
 
     def _ln_bwd(self, kw, x, res, y, g, b, H, bias_name):
         M = x.M
-        nblk = ops.ln_bwd_blocks(M)
+        nblk = ops.ln_bwd_blocks(M, H, LN_RESID)
         partial = self.arena.alloc(nblk * 3 * H, torch.float32)
         if res is not None:
             if res.g is not None:
                 raise GstvdError("internal: residual gradient written twice")
             res.g = self.buf(M, H)
         x.g = self.buf(M, H)
-        ops.ln_bwd(kw, y.g, partial, dres=res.g if res is not None else None, dx=x.g)
+        ops.ln_bwd(kw, y.g, partial, dres=res.g if res is not None else None, dx=x.g, nblk=nblk)
         self._colsums(partial, nblk, H, [g, b, bias_name])
         x.bias_done = bias_name is not None
 

@@ -294,14 +294,18 @@ def ln_fwd(**kw):
     _prof_end(e0, "ln_fwd", 0.0, 3.0 * d.M * d.H * (2 if d.dtype == BF16 else 4), (d.M, d.H, d.mode))
 
 
-def ln_bwd_blocks(M):
-    return int(L.load().gstvd_ln_bwd_blocks(M))
+def ln_bwd_blocks(M, H=None, mode=None):
+    """Number of column-partial slabs the backward kernel writes for this geometry (size `partial` with it and pass it on)."""
+    if H is None:
+        return int(L.load().gstvd_ln_bwd_blocks(M))
+    return int(L.load().gstvd_ln_bwd_blocks_for(M, H, mode))
 
 
-def ln_bwd(fwd_kw, dy, partial, dres=None, dx=None, dword=None, dpos=None, dtt=None, dtt_ext=None):
+def ln_bwd(fwd_kw, dy, partial, dres=None, dx=None, dword=None, dpos=None, dtt=None, dtt_ext=None, nblk=0):
     lib = L.load()
     b = L.LnBwdDesc()
     b.f = _ln_desc(**fwd_kw)
+    b.nblk = nblk
     b.dy, b.lddy = _p(dy), dy.stride(-2)
     b.dres, b.lddres = _p(dres), (dres.stride(-2) if dres is not None else 0)
     b.dx, b.lddx = _p(dx), (dx.stride(-2) if dx is not None else 0)

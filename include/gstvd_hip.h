@@ -128,8 +128,10 @@ typedef struct {
   void* dx; int64_t lddx;       /* RESID: gradient wrt x (may alias dres when p_pre == 0) */
   float* partial;
   float* dword; float* dpos; float* dtt; float* dtt_ext; /* EMBED */
+  int64_t nblk;   /* number of [3|4][H] slabs `partial` holds = gstvd_ln_bwd_blocks_for(M, H, mode); 0 = gstvd_ln_bwd_blocks(M) */
 } gstvd_ln_bwd_t;
-int64_t gstvd_ln_bwd_blocks(int64_t M);
+int64_t gstvd_ln_bwd_blocks(int64_t M);                                    /* upper bound for every (H, mode) */
+int64_t gstvd_ln_bwd_blocks_for(int64_t M, int64_t H, int32_t mode);       /* the geometry gstvd_ln_bwd uses when told so via nblk */
 int gstvd_ln_bwd(const gstvd_ln_bwd_t* p, gstvd_stream_t s);
 
 /* out_j[c] (+)= sum_blk partial[blk, j, c]  for j in 0..nvec-1 ; out_j may be NULL (skipped) */
