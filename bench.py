@@ -161,6 +161,7 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="diagnostic: no backward pipeline (wgrad/AdamW after backward, same stream)")
     ap.add_argument("--chunk-melems", type=int, default=0,
                     help="backward-pipeline slice size in Mi elements (0 = auto: 192 at N=1, 40 at N>1)")
+    ap.add_argument("--chunk-list", default="", help="graded backward-pipeline slice sizes in Mi elements, comma separated (overrides --chunk-melems)")
     ap.add_argument("--no-streams", action="store_true", help="run the vision stream on the main HIP stream")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 parity-mode timing beside the bf16 headline")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive measurement (inputs staged from pinned host memory)")
@@ -216,7 +217,9 @@ def main():
     # Slice size: at N>1 many slices let each all-reduce overlap the rest of backward and keep the exposed tail (last
     # slice's wgrad + all-reduce + AdamW) short; at N=1 there is nothing to hide and two large slices are faster (measured
     # 15.4 ms at 40 Mi, 14.8 ms at 192 Mi: the grouped wgrad launches are larger, AdamW streams less often through L2)
-    if args.chunk_melems:
+    if args.chunk_list:
+        chunk_elems = [int(c) << 20 for c in args.chunk_list.split(",")]
+    elif args.chunk_melems:
         chunk_elems = args.chunk_melems << 20
     elif world > 1 or force_dist:
         # graded: the decoder + LM head (first to finish) go out as one large slice, the encoder's follow in shrinking
