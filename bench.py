@@ -167,6 +167,10 @@ def main():
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive measurement (inputs staged from pinned host memory)")
     args = ap.parse_args()
 
+    # torch's OpenMP pool on a 256-logical-CPU host: workers that keep spinning after a parallel CPU tensor op starve the ROCm
+    # runtime's threads and slow hipGraph replays (measured 2x); the GPU legs need no CPU parallelism,
+    # the CPU baseline sets its own thread count later
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
