@@ -13,6 +13,7 @@ ABI_VERSION = 2
 
 F32, BF16 = 0, 1
 EPI_BIAS, EPI_ADD, EPI_GELU, EPI_DGELU, EPI_DROPOUT = 1, 2, 4, 8, 16
+EPI_COLSUM, EPI_COLSUM_ACC = 32, 64
 LN_RESID, LN_EMBED, LN_IMAGE = 0, 1, 2
 
 _vp, _i64, _i32, _f32, _u32 = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_uint32
@@ -71,6 +72,7 @@ SIGNATURES = {
     "gstvd_gemm_splitk_ws_bytes": (_i64, [_i64, _i64, _i32]),
     "gstvd_gemm_splitk": (_i32, [_vp, _i32, _vp, _i64, _vp]),
     "gstvd_gemm_group_tile": (_i32, []),
+    "gstvd_gemm_group_caps": (_i32, []),
     "gstvd_debug_gemm_clock": (_i32, [_vp, _i32]),
     "gstvd_gemm_kernel_name": (_i32, [C.POINTER(GemmDesc), _i32, C.c_char_p, _i32]),
     "gstvd_gemm_grouped_kernel_name": (_i32, [_i32, _i32, _i32, _i32, C.c_char_p, _i32]),

@@ -373,7 +373,7 @@ DEVFN void pp_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char*
 // issuing DMA and both waves of a SIMD do so at the same time (section 5 of DESIGN.md: 1358 cycles per step without any DMA
 // instruction, 1725 with); here the consumers' step IS that DMA-free loop and the DMA issue runs beside it on a third wave of
 // the SIMD.  Needs <= 168 VGPRs (three waves per SIMD).
-template <typename OT, bool AKM, bool BKM, int NIU = 4>
+template <typename OT, bool AKM, bool BKM, int NIU = 4, bool CS = false>
 DEVFN void pc_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char* smem) {
   constexpr int BM = 256, BN = 256, WN = 4, NS = NS256, NTP = 256;
   constexpr int WTM = 128, WTN = NIU * 16, MI = 8, NI = NIU, BNU = WN * WTN;
@@ -402,17 +402,55 @@ DEVFN void pc_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char*
       ua.issue(s, p.K, smem + s * STAGE, pw);
       ub.issue(s, p.K, smem + s * STAGE + A_BYTES, pw);
     }
-    int fill = NS - 1;
+    int fill = NS - 1, slot = 0;
+    // CS (grouped weight gradients, k-major A = dY): the producers of the tiles in column block 0 also sum the A image over k
+    // while it sits in the ring -- bias[m] = sum over the batch rows of dY[row][m], the bias gradient -- instead of a separate
+    // pass over dY (colsum_slab_batched: 0.25 ms per step, a 0.7 GB re-read).  Lane = (row group rg = lane >> 3, column group
+    // cg = 8 * wave + (lane & 7)): thread reads the 16-byte unit of columns 8cg..8cg+7 in k-rows 4rg..4rg+3 of every stage;
+    // the eight row groups of a column group sit in one wave, so the final reduction is three shuffles, no LDS, no barrier.
+    const bool do_cs = CS && AKM && (p.epi & GSTVD_EPI_COLSUM) && n0 == 0 && p.bias != nullptr;
+    const int rg = lane >> 3, cg = pw * 8 + (lane & 7);
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int64_t t = 0; t < nkt; ++t) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPS) : "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       ua.issue(t + NS - 1, p.K, smem + fill * STAGE, pw);
       ub.issue(t + NS - 1, p.K, smem + fill * STAGE + A_BYTES, pw);
+      if (CS && do_cs) {
+        const char* cA = smem + slot * STAGE;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bf16x8 v = *(const bf16x8*)(cA + km32_off<BM>(rg * 4 + r, cg * 8));
+#pragma unroll
+          for (int e = 0; e < 8; ++e) cs[e] += (float)v[e];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads are done before this wave releases the slot at the next barrier
+      }
       fill = (fill + 1 == NS) ? 0 : fill + 1;
+      slot = (slot + 1 == NS) ? 0 : slot + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the ring's trailing (zero page) pieces
     __builtin_amdgcn_s_barrier();                          // pairs with the consumers' barrier in front of the epilogue
+    if (CS && do_cs) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = cs[e];
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        cs[e] = v;
+      }
+      if (rg == 0) {
+        const bool accb = (p.epi & GSTVD_EPI_COLSUM_ACC) != 0;
+        float* out = const_cast<float*>(p.bias);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int64_t m = m0 + cg * 8 + e;
+          if (m < p.M) out[m] = accb ? out[m] + cs[e] : cs[e];
+        }
+      }
+    }
     return;
   }
 
@@ -598,7 +636,7 @@ __global__ __launch_bounds__(768) void gemm_pc256_grouped_kernel(const gstvd_gem
   p.sA = p.sB = p.sC = p.sAdd = p.sAux = 0;
   p.epi = g.epilogue; p.alpha = g.alpha; p.p = g.dropout_p; p.site = g.site; p.rng = g.rng;
   const int ntn = (int)((g.N + 255) / 256), ntm = (int)((g.M + 255) / 256);
-  pc_tile256<OT, AKM, BKM, 4>(p, 0, gid - tile_off[lo], ntn, ntm * ntn, smem);
+  pc_tile256<OT, AKM, BKM, 4, true>(p, 0, gid - tile_off[lo], ntn, ntm * ntn, smem);
 }
 
 template <typename OT, bool AKM, bool BKM>
@@ -627,6 +665,13 @@ static int grouped256(const gstvd_gemm_t* tab, const int* off, int nprob, int to
 }
 
 extern "C" int gstvd_gemm_group_tile(void) { return 256; }
+
+extern "C" int32_t gstvd_gemm_group_caps(void) {
+  const char* e = getenv("GSTVD_GEMM_PC");
+  const char* t = getenv("GSTVD_GEMM_ST");
+  const bool pc = (e ? atoi(e) : 1) != 0 && (t ? atoi(t) : 0) == 0;
+  return pc ? 1 : 0;
+}
 
 // symbol of the grouped kernel for a (dtype, layout) combination -- same plan-only mechanism as gstvd_gemm_kernel_name
 extern "C" int gstvd_gemm_grouped_kernel_name(int32_t dtype_in, int32_t dtype_out, int32_t a_kmajor, int32_t b_kmajor, char* buf,

@@ -476,11 +476,17 @@ class Engine(object):
     def _lin_bwd(self, x, y, w, b, N, K, need_dx):
         dy, M = y.g, x.M      # for a GELU output y.g already holds d(pre-activation): its producer applied gelu'
         gw, acc = self.grad_slot(w)
-        self.wgrads.add(dy, x.t, gw, N, K, M, acc)       # deferred: all weight-gradient GEMMs run as one grouped launch
-        if not y.bias_done:
+        if not y.bias_done and self.wgrads.colsum_capable(dy):
+            # the bias gradient (column sums of dY) comes out of the weight-gradient launch itself: its producer waves sum the
+            # dY tiles they stage anyway
             gb, accb = self.grad_slot(b)
-            scratch = self.vec(((M + 63) // 64) * N)
-            self.colsums.add_slabs(dy, M, N, scratch, gb, accb)
+            self.wgrads.add(dy, x.t, gw, N, K, M, acc, colsum_out=gb, colsum_acc=accb)
+        else:
+            self.wgrads.add(dy, x.t, gw, N, K, M, acc)   # deferred: all weight-gradient GEMMs run as one grouped launch
+            if not y.bias_done:
+                gb, accb = self.grad_slot(b)
+                scratch = self.vec(((M + 63) // 64) * N)
+                self.colsums.add_slabs(dy, M, N, scratch, gb, accb)
         if need_dx:
             add = x.g
             if x.g is None:

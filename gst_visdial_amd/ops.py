@@ -201,14 +201,25 @@ class GemmGroup(object):
         self.device, self.a_km, self.b_km = device, a_km, b_km
         self.items, self.cache, self.keep = [], {}, []
         self.dtype_in = self.dtype_out = None
+        self._caps = None
 
-    def add(self, A, B, C_out, M, N, K, accumulate):
+    def colsum_capable(self, A):
+        """True when a grouped launch of this group can also produce bias[m] = sum_k A[k][m] (GSTVD_EPI_COLSUM): bf16 operands
+        (the grouped kernel), k-major A, and the library says its grouped launch honours the flag."""
+        if not (self.a_km and A.dtype == torch.bfloat16):
+            return False
+        if self._caps is None:
+            self._caps = int(L.load().gstvd_gemm_group_caps())
+        return bool(self._caps & 1)
+
+    def add(self, A, B, C_out, M, N, K, accumulate, colsum_out=None, colsum_acc=False):
         di, do = dt(A), dt(C_out)
         if self.items and (di, do) != (self.dtype_in, self.dtype_out):
             self.flush()
         self.dtype_in, self.dtype_out = di, do
-        self.keep.append((A, B, C_out))      # keep the operands alive until the launch
-        self.items.append((_p(A), _p(B), _p(C_out), M, N, K, A.stride(-2), B.stride(-2), C_out.stride(-2), int(bool(accumulate))))
+        self.keep.append((A, B, C_out, colsum_out))      # keep the operands alive until the launch
+        cs = (_p(colsum_out), int(bool(colsum_acc))) if colsum_out is not None else (0, 0)
+        self.items.append((_p(A), _p(B), _p(C_out), M, N, K, A.stride(-2), B.stride(-2), C_out.stride(-2), int(bool(accumulate))) + cs)
 
     def reset(self):
         self.items, self.keep = [], []
@@ -219,7 +230,9 @@ class GemmGroup(object):
         keep, self.keep = self.keep, []      # released when this call returns (after the launch is enqueued)
         if self.dtype_in != BF16:            # fp32 parity mode: plain launches
             lib = L.load()
-            for (a, b, c, M, N, K, lda, ldb, ldc, acc) in self.items:
+            for (a, b, c, M, N, K, lda, ldb, ldc, acc, cs_ptr, cs_acc) in self.items:
+                if cs_ptr:
+                    raise L.GstvdError("column sums ride on the grouped bf16 launch only")
                 d = L.GemmDesc()
                 d.A, d.B, d.C, d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.batch = a, b, c, M, N, K, lda, ldb, ldc, 1
                 d.dtype_in, d.dtype_out, d.a_kmajor, d.b_kmajor, d.alpha = self.dtype_in, self.dtype_out, int(self.a_km), int(self.b_km), 1.0
@@ -235,11 +248,14 @@ class GemmGroup(object):
             offs, tiles, flops, nbytes = [], 0, 0.0, 0.0
             esz_in, esz_out = (2 if self.dtype_in == BF16 else 4), (2 if self.dtype_out == BF16 else 4)
             T = int(L.load().gstvd_gemm_group_tile())
-            for d, (a, b, c, M, N, K, lda, ldb, ldc, acc) in zip(arr, key):
+            for d, (a, b, c, M, N, K, lda, ldb, ldc, acc, cs_ptr, cs_acc) in zip(arr, key):
                 d.A, d.B, d.C, d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.batch = a, b, c, M, N, K, lda, ldb, ldc, 1
                 d.dtype_in, d.dtype_out, d.a_kmajor, d.b_kmajor, d.alpha = self.dtype_in, self.dtype_out, int(self.a_km), int(self.b_km), 1.0
                 if acc:
                     d.addend, d.ldadd, d.epilogue = c, ldc, EPI_ADD
+                if cs_ptr:                      # bias[m] (+)= sum_k A[k][m] out of the same launch
+                    d.bias = cs_ptr
+                    d.epilogue |= L.EPI_COLSUM | (L.EPI_COLSUM_ACC if cs_acc else 0)
                 offs.append(tiles)
                 tiles += ((M + T - 1) // T) * ((N + T - 1) // T)
                 flops += 2.0 * M * N * K

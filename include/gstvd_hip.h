@@ -52,7 +52,11 @@ const char* gstvd_build_arch(void);     /* "gfx950" */
  * k-major operands need their M (resp. N) extent % (16/sizeof(T)) == 0.  M and the k extent of
  * k-major operands are arbitrary (predicated / zero filled).
  */
-enum { GSTVD_EPI_BIAS = 1, GSTVD_EPI_ADD = 2, GSTVD_EPI_GELU = 4, GSTVD_EPI_DGELU = 8, GSTVD_EPI_DROPOUT = 16 };
+enum { GSTVD_EPI_BIAS = 1, GSTVD_EPI_ADD = 2, GSTVD_EPI_GELU = 4, GSTVD_EPI_DGELU = 8, GSTVD_EPI_DROPOUT = 16,
+       /* grouped weight-gradient launches only (gstvd_gemm_grouped with a k-major A, see gstvd_gemm_group_caps):
+        * bias[m] (=|+=) sum_k A[k][m] -- the bias gradient dY^T.1 that autograd computes next to dW = dY^T X, taken from the
+        * dY tiles the launch stages anyway (the tiles of column block 0 do it); COLSUM_ACC adds to bias instead of overwriting */
+       GSTVD_EPI_COLSUM = 32, GSTVD_EPI_COLSUM_ACC = 64 };
 
 typedef struct {
   const void* A; const void* B; void* C;
@@ -241,6 +245,8 @@ int gstvd_adamw_bf16grad(float* param, const void* grad_bf16, int64_t grad_origi
 /* Measurement support: the (mangled) symbol of the device kernel that gstvd_gemm (splits <= 1) or gstvd_gemm_splitk
  * (splits >= 2) would launch for this descriptor -- the dispatch runs, the launch is replaced by recording its target.
  * bench.py's roofline.kernel comes from here.  Nothing is launched; pointers in the descriptor are not dereferenced. */
+/* bit 0: gstvd_gemm_grouped honours GSTVD_EPI_COLSUM (the producer / consumer kernel is the one it launches) */
+int32_t gstvd_gemm_group_caps(void);
 int gstvd_gemm_kernel_name(const gstvd_gemm_t* g, int32_t splits, char* buf, int32_t buf_len);
 int gstvd_gemm_grouped_kernel_name(int32_t dtype_in, int32_t dtype_out, int32_t a_kmajor, int32_t b_kmajor, char* buf, int32_t buf_len);
 

@@ -455,6 +455,40 @@ def test_gemm_grouped_matches_individual_launches():
         check("gemm_grouped_%d" % i, dw, ref, torch.bfloat16, 2.0)
 
 
+def test_gemm_grouped_column_sums():
+    """GSTVD_EPI_COLSUM: the grouped weight-gradient launch also returns the bias gradient sum_rows dy[row][:] (overwrite and
+    accumulate forms; ragged row counts and widths below / across the 256 tile; a problem without the flag in the same launch)."""
+    o = ops()
+    grp = o.GemmGroup(DEV, a_km=True, b_km=True)
+    refs = []
+    cases = [(333, 128, 256, False, "set"), (592, 1024, 256, True, "acc"), (100, 64, 96, False, "acc"), (4096, 768, 768, False, "set"),
+             (77, 300, 520, False, None), (1, 264, 32, False, "set")]
+    for i, (rows, N, K, acc, cs) in enumerate(cases):
+        dy, x = rnd(rows, N, dtype=torch.bfloat16, seed=190 + i), rnd(rows, K, dtype=torch.bfloat16, seed=195 + i)
+        assert grp.colsum_capable(dy)
+        dw, gb = rnd(N, K, seed=199 + i), rnd(N, seed=205 + i)
+        ref = dy.float().t() @ x.float() + (dw if acc else 0)
+        gb_ref = gb.clone() if cs is None else dy.double().sum(0).float() + (gb if cs == "acc" else 0)
+        if cs is None:
+            grp.add(dy, x, dw, N, K, rows, acc)
+        else:
+            grp.add(dy, x, dw, N, K, rows, acc, colsum_out=gb, colsum_acc=(cs == "acc"))
+        refs.append((dw, ref, gb, gb_ref, rows))
+    grp.flush()
+    for i, (dw, ref, gb, gb_ref, rows) in enumerate(refs):
+        check("gemm_grouped_cs_%d" % i, dw, ref, torch.bfloat16, 2.0)
+        # fp32 sums of bf16 values: only the summation order differs from the float64 reference
+        assert (gb - gb_ref).abs().max().item() <= 1e-5 * max(1.0, rows ** 0.5) * max(1.0, gb_ref.abs().max().item()), i
+    # replays of the same group (the captured train step) keep working: second launch, accumulate form adds again
+    dw, ref, gb, gb_ref, rows = refs[3]
+    before = gb.clone()
+    grp2 = o.GemmGroup(DEV, a_km=True, b_km=True)
+    dy = rnd(4096, 768, dtype=torch.bfloat16, seed=193)
+    grp2.add(dy, rnd(4096, 768, dtype=torch.bfloat16, seed=198), dw, 768, 768, 4096, False, colsum_out=gb, colsum_acc=True)
+    grp2.flush()
+    assert torch.allclose(gb, before + dy.float().sum(0), rtol=1e-5, atol=1e-3)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_attention_kv_cache_strides_and_shared_kv(dtype):
     """Forward-only descriptor extras: Lq = 1 against a partially filled [B, Umax, H] cache (kv_bstride) and K/V shared
