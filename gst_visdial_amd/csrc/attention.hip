@@ -14,8 +14,13 @@
 //     is therefore already a legal MFMA B operand (k = 4*(lane>>4)+j) and never visits LDS;
 //   * the second product reads its A operand (V^T, K^T, dO^T, Q^T) with ds_read_b64_tr_b16 from the
 //     row-major LDS image, i.e. the transpose is free;
-//   * softmax statistics: online max/sum per query column in registers, 2 shuffles per 16-key tile;
-//     forward saves only LSE; backward recomputes P = exp(s - LSE) and regenerates the dropout mask;
+//   * softmax statistics: online max/sum per query column in registers, updated once per 64-key chunk (d <= 64) or 32 keys
+//     (d = 128) with two v_permlane swaps; forward saves only LSE; backward recomputes P = exp(s - LSE) and regenerates the
+//     dropout mask;
+//   * the kernels are bound by VALU issue and dependent-latency chains, not by MFMA or memory (rocprofv3 SQ counters of the
+//     text shape: VALU active 0.21 of wave cycles x 3 waves per SIMD, MFMA pipe busy < 0.15, no LDS bank conflicts): tiles
+//     are processed several at a time (independent first products in flight, one statistics update, pairs of tiles on one
+//     16x16x32 second product) and the dropout draws use 32-bit index arithmetic when the launch allows it;
 //   * fp32 parity mode runs the same skeleton on v_mfma_f32_16x16x4_f32.
 #include "common.h"
 #include <math.h>
@@ -179,12 +184,77 @@ DEVFN void second_product(f32x4 (&acc)[D / 16], const char* img_tr, int xb, cons
 
 DEVFN int round4(int x) { return (x + 3) & ~3; }
 
+// The second product of TWO 16-row tiles (rows xb.. and xb+16..).  bf16: ONE 16x16x32 MFMA per 16 output columns -- k-slot 8g+j
+// of the instruction is row 4g+j of the first tile (j < 4) or of the second (j >= 4), i.e. the A operand is the concatenation
+// of the two transposed reads the tiles would have issued separately and the B operand that of their in-register weights.
+template <typename T, int D>
+DEVFN void second_product_pair(f32x4 (&acc)[D / 16], const char* img_tr, int xb, const float (&w0)[4], const float (&w1)[4], int lane) {
+  if constexpr (sizeof(T) == 2) {
+    const int g = lane >> 4, li = lane & 15;
+    const bf16x8 b = {(bf16)w0[0], (bf16)w0[1], (bf16)w0[2], (bf16)w0[3], (bf16)w1[0], (bf16)w1[1], (bf16)w1[2], (bf16)w1[3]};
+#pragma unroll
+    for (int i = 0; i < D / 16; ++i) {
+      const s16x4 lo = lds_tr16(img_tr + Img<T, D>::tr_off(xb + 4 * g + (li >> 2), i * 16 + 4 * (lane & 3)));
+      const s16x4 hi = lds_tr16(img_tr + Img<T, D>::tr_off(xb + 16 + 4 * g + (li >> 2), i * 16 + 4 * (lane & 3)));
+      typedef __attribute__((ext_vector_type(8))) short s16x8;
+      const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      acc[i] = mfma_bf16_k32(__builtin_bit_cast(bf16x8, v), b, acc[i]);
+    }
+  } else {
+    second_product<T, D>(acc, img_tr, xb, w0, lane);
+    second_product<T, D>(acc, img_tr, xb + 16, w1, lane);
+  }
+}
+
+// Reductions over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48), result in every lane: two gfx950 lane swaps
+// inside the VALU instead of two dependent ds_bpermute round trips (~100 cycles each) through the LDS crossbar.
+//   v_permlane16_swap a, b: rows 1, 3 of a <-> rows 0, 2 of b;   v_permlane32_swap a, b: rows 2, 3 of a <-> rows 0, 1 of b.
+DEVFN void rows_swap16(float& x, float& y) { asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y)); }
+DEVFN void rows_swap32(float& x, float& y) { asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y)); }
+DEVFN float rows_max(float v) {
+  float w = v;
+  rows_swap16(v, w);
+  v = fmaxf(v, w); w = v;
+  rows_swap32(v, w);
+  return fmaxf(v, w);
+}
+DEVFN float rows_sum(float v) {
+  float w = v;
+  rows_swap16(v, w);
+  v += w; w = v;
+  rows_swap32(v, w);
+  return v + w;
+}
+
+// Dropout draws.  E32: the launch has fewer than 2^33 score elements, so the high word of every pair index is zero and its
+// term of drop_draw (a quarter-rate integer multiply per draw) vanishes -- same stream, cheaper arithmetic.
+template <bool E32> DEVFN uint32_t draw_pair(const DropKey& k, uint64_t e2) {
+  if (E32) return mix32((uint32_t)e2 ^ k.key);
+  return drop_draw(k, e2);
+}
+template <bool E32> DEVFN f32x4 drop_factor4e(const DropKey& k, uint64_t e) {      // four consecutive elements, e % 4 == 0
+  f32x4 f = {1.f, 1.f, 1.f, 1.f};
+  if (!k.on) return f;
+  const uint32_t r0 = draw_pair<E32>(k, e >> 1), r1 = draw_pair<E32>(k, (e >> 1) + 1);
+  f[0] = (r0 & 0xffffu) >= k.thr ? k.scale : 0.f;
+  f[1] = (r0 >> 16) >= k.thr ? k.scale : 0.f;
+  f[2] = (r1 & 0xffffu) >= k.thr ? k.scale : 0.f;
+  f[3] = (r1 >> 16) >= k.thr ? k.scale : 0.f;
+  return f;
+}
+
+// The three bodies below work on a whole 64-row chunk at a time: the first products of its (up to four) 16x16 tiles are issued
+// together, the element-wise part runs on 16 values per lane, the softmax statistics are updated ONCE per chunk, and the second
+// products pair tiles on 16x16x32 MFMAs.  The kernels are bound by VALU issue (exp, the dropout hash, bf16 packing -- not by
+// MFMA or memory), so per-tile bookkeeping (two cross-lane maxima, a ballot, the accumulator rescale with its AGPR<->VGPR
+// copies, loop and address arithmetic) was half of the instruction stream when it ran once per 16 keys.
+
 // =====================================================================================================
 // forward
 // =====================================================================================================
-template <typename T, int D>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(gstvd_attn_t a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+template <typename T, int D, bool E32>
+DEVFN void attn_fwd_body(const gstvd_attn_t& a, char* smem) {
+  constexpr int TF = D <= 64 ? 4 : 2;                         // 16-key tiles per softmax update
   char* sK = smem;
   char* sV = smem + Img<T, D>::BYTES;
   float* smask = (float*)(smem + 2 * Img<T, D>::BYTES);
@@ -201,7 +271,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(gstvd_attn_t a) {
   qf.load(Qb + (int64_t)q * a.ldq, qv, g);
   const DropKey dk = make_drop(a.dropout_p, a.site, a.rng);
   const int Lkp = round4(a.Lk);
-  const uint64_t ebase = ((uint64_t)(b * a.nh + h) * a.Lq + (uint64_t)(qv ? q : 0)) * (uint64_t)Lkp;
+  const uint64_t ebase = ((uint64_t)(b * a.nh + h) * a.Lq + (uint64_t)(qv ? q : 0)) * (uint64_t)Lkp + (uint64_t)(4 * g);
 
   float m_run = -1e30f, l_part = 0.f;
   f32x4 accO[D / 16];
@@ -229,31 +299,34 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(gstvd_attn_t a) {
     __syncthreads();
     if (c0 + 64 < a.Lk) prefetch(c0 + 64);
     const int ntile = (a.Lk - c0 + 15) / 16 < 4 ? (a.Lk - c0 + 15) / 16 : 4;
-    for (int t = 0; t < ntile; ++t) {
-      f32x4 s = first_product<T, D>(sK, t * 16, qf, lane);
-      f32x4 madd = *(const f32x4*)(smask + t * 16 + 4 * g);
-      if (a.causal) {
+    // TF tiles per softmax update: the whole chunk for d <= 64, half of it for d = 128 (register budget of two waves per SIMD)
+#pragma unroll 1
+    for (int hf = 0; hf < 4 / TF; ++hf) {
+      const int nt = ntile - TF * hf, k0 = 16 * TF * hf;
+      if (nt <= 0) break;
+      f32x4 s[TF];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (c0 + t * 16 + 4 * g + r > q && madd[r] == 0.f) madd[r] = a.mask_neg;     // causal x padding: the term is added once
-      }
-      float val[4], mx = -INFINITY;
+      for (int t = 0; t < TF; ++t)
+        if (t < nt) s[t] = first_product<T, D>(sK, k0 + t * 16, qf, lane);
+      float val[TF][4], mx = -INFINITY;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        val[r] = s[r] * a.scale + madd[r];
-        mx = fmaxf(mx, val[r]);
+      for (int t = 0; t < TF; ++t) {
+        if (t < nt) {
+          f32x4 madd = *(const f32x4*)(smask + k0 + t * 16 + 4 * g);
+          if (a.causal) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (c0 + k0 + t * 16 + 4 * g + r > q && madd[r] == 0.f) madd[r] = a.mask_neg;   // causal x padding: the term is added once
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            val[t][r] = s[t][r] * a.scale + madd[r];
+            mx = fmaxf(mx, val[t][r]);
+          }
+        }
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = rows_max(mx);
       const float m_new = fmaxf(m_run, mx);
-      const f32x4 fac = drop_factor4(dk, ebase + (uint64_t)(c0 + t * 16 + 4 * g));
-      float pd[4], ps = 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = __expf(val[r] - m_new);
-        ps += p;
-        pd[r] = p * fac[r];
-      }
       if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {       // the running max moved for some query of this wave
         const float alpha = __expf(m_run - m_new);
         l_part *= alpha;
@@ -261,12 +334,28 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(gstvd_attn_t a) {
         for (int i = 0; i < D / 16; ++i) accO[i] *= alpha;
         m_run = m_new;
       }
+      float pd[TF][4], ps = 0.f;
+#pragma unroll
+      for (int t = 0; t < TF; ++t) {
+        if (t < nt) {
+          const f32x4 fac = drop_factor4e<E32>(dk, ebase + (uint64_t)(c0 + k0 + t * 16));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = __expf(val[t][r] - m_new);
+            ps += p;
+            pd[t][r] = p * fac[r];
+          }
+        }
+      }
       l_part += ps;
-      second_product<T, D>(accO, sV, t * 16, pd, lane);
+#pragma unroll
+      for (int pr = 0; pr < TF / 2; ++pr) {
+        if (2 * pr + 1 < nt) second_product_pair<T, D>(accO, sV, k0 + 32 * pr, pd[2 * pr], pd[2 * pr + 1], lane);
+        else if (2 * pr < nt) second_product<T, D>(accO, sV, k0 + 32 * pr, pd[2 * pr], lane);
+      }
     }
   }
-  float l_tot = l_part + __shfl_xor(l_part, 16, 64);
-  l_tot += __shfl_xor(l_tot, 32, 64);
+  const float l_tot = rows_sum(l_part);
   const float inv = 1.f / l_tot;
   if (qv) {
     T* Op = (T*)a.O + ((int64_t)b * qbs + q) * a.ldo + h * D;
@@ -276,12 +365,28 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(gstvd_attn_t a) {
   }
 }
 
+DEVFN bool attn_small_index_space(const gstvd_attn_t& a) {
+  return (uint64_t)a.B * (uint64_t)a.nh * (uint64_t)a.Lq * (uint64_t)round4(a.Lk) < (1ull << 33);
+}
+
+// Occupancy: the grids of the step give 2-3 waves per SIMD (d = 64) and ~2 (d = 128); the register budgets below keep exactly
+// that many resident (left to itself the compiler takes up to 440 registers for the chunk-wide bodies: one wave per SIMD).
+template <typename T, int D>
+__global__ __launch_bounds__(256, (D <= 64 ? 3 : 2)) void attn_fwd_kernel(gstvd_attn_t a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if constexpr (sizeof(T) == 2) {
+    if (attn_small_index_space(a)) { attn_fwd_body<T, D, true>(a, smem); return; }
+  }
+  attn_fwd_body<T, D, false>(a, smem);
+}
+
 // =====================================================================================================
 // backward, part 1: dQ (and delta = rowsum(dO * O)); same tiling as forward
 // =====================================================================================================
-template <typename T, int D>
+template <typename T, int D, bool E32>
 DEVFN void attn_bwd_dq_body(const gstvd_attn_t& a, const int bx, char* smem) {
   constexpr bool BF = Img<T, D>::BF;
+  constexpr int TP = D <= 64 ? 2 : 1;                         // 16-key tiles per inner iteration
   char* sKr = smem;                                           // row image of K
   char* sKt = BF ? smem + Img<T, D>::BYTES : smem;            // transposed-read image of K
   char* sVr = smem + (BF ? 2 : 1) * Img<T, D>::BYTES;         // row image of V
@@ -298,15 +403,13 @@ DEVFN void attn_bwd_dq_body(const gstvd_attn_t& a, const int bx, char* smem) {
   RowFrag<T, D> qf, dof;
   qf.load(Qb + (int64_t)q * a.ldq, qv, g);
   dof.load(dOb + (int64_t)q * a.lddo, qv, g);
-  float delta = dof.dot(Ob + (int64_t)q * a.ldo, qv, g);
-  delta += __shfl_xor(delta, 16, 64);
-  delta += __shfl_xor(delta, 32, 64);
+  float delta = rows_sum(dof.dot(Ob + (int64_t)q * a.ldo, qv, g));
   const int64_t stat = ((int64_t)b * a.nh + h) * a.Lq + q;
   if (qv && g == 0) a.delta[stat] = delta;
-  const float lse = qv ? a.LSE[stat] : 0.f;
+  const float lse = qv ? a.LSE[stat] : INFINITY;              // +inf => p = 0 for padded query rows
   const DropKey dk = make_drop(a.dropout_p, a.site, a.rng);
   const int Lkp = round4(a.Lk);
-  const uint64_t ebase = ((uint64_t)(b * a.nh + h) * a.Lq + (uint64_t)(qv ? q : 0)) * (uint64_t)Lkp;
+  const uint64_t ebase = ((uint64_t)(b * a.nh + h) * a.Lq + (uint64_t)(qv ? q : 0)) * (uint64_t)Lkp + (uint64_t)(4 * g);
 
   f32x4 acc[D / 16];
 #pragma unroll
@@ -332,24 +435,43 @@ DEVFN void attn_bwd_dq_body(const gstvd_attn_t& a, const int bx, char* smem) {
     __syncthreads();
     if (c0 + 64 < a.Lk) prefetch(c0 + 64);
     const int ntile = (a.Lk - c0 + 15) / 16 < 4 ? (a.Lk - c0 + 15) / 16 : 4;
-    for (int t = 0; t < ntile; ++t) {
-      const f32x4 s = first_product<T, D>(sKr, t * 16, qf, lane);
-      const f32x4 dp = first_product<T, D>(sVr, t * 16, dof, lane);
-      const f32x4 fac = drop_factor4(dk, ebase + (uint64_t)(c0 + t * 16 + 4 * g));
-      f32x4 madd = *(const f32x4*)(smask + t * 16 + 4 * g);
-      if (a.causal) {
+    // TP tiles at a time.  d <= 64: two (32 keys) -- enough to pair them on the 16x16x32 second product and to halve the
+    // per-tile bookkeeping, few enough live values for three waves per SIMD (a whole chunk at once needed 296 registers in the
+    // merged kernel: one wave per SIMD, 105 us instead of 61 for the text shape).  d = 128: one -- the accumulators, operand
+    // fragments and prefetch registers of that width leave no room for a second tile at two waves per SIMD.
+#pragma unroll 1
+    for (int pr = 0; pr < 4 / TP; ++pr) {
+      const int nt = ntile - TP * pr;
+      if (nt <= 0) break;
+      f32x4 s[TP], dp[TP];
+      float ds[TP][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (c0 + t * 16 + 4 * g + r > q && madd[r] == 0.f) madd[r] = a.mask_neg;
+      for (int tt = 0; tt < TP; ++tt) {
+        if (tt < nt) {
+          s[tt] = first_product<T, D>(sKr, 16 * TP * pr + tt * 16, qf, lane);
+          dp[tt] = first_product<T, D>(sVr, 16 * TP * pr + tt * 16, dof, lane);
+        }
       }
-      float ds[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float val = s[r] * a.scale + madd[r];
-        const float p = qv ? __expf(val - lse) : 0.f;
-        ds[r] = p * (dp[r] * fac[r] - delta) * a.scale;
+      for (int tt = 0; tt < TP; ++tt) {
+        if (tt < nt) {
+          const int k0 = 16 * TP * pr + tt * 16;
+          const f32x4 fac = drop_factor4e<E32>(dk, ebase + (uint64_t)(c0 + k0));
+          f32x4 madd = *(const f32x4*)(smask + k0 + 4 * g);
+          if (a.causal) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (c0 + k0 + 4 * g + r > q && madd[r] == 0.f) madd[r] = a.mask_neg;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = __expf(s[tt][r] * a.scale + madd[r] - lse);
+            ds[tt][r] = p * (dp[tt][r] * fac[r] - delta) * a.scale;
+          }
+        }
       }
-      second_product<T, D>(acc, sKt, t * 16, ds, lane);
+      if (TP > 1 && nt > 1) second_product_pair<T, D>(acc, sKt, 16 * TP * pr, ds[0], ds[TP - 1], lane);
+      else second_product<T, D>(acc, sKt, 16 * TP * pr, ds[0], lane);
     }
   }
   if (qv) {
@@ -362,10 +484,11 @@ DEVFN void attn_bwd_dq_body(const gstvd_attn_t& a, const int bx, char* smem) {
 // =====================================================================================================
 // backward, part 2: dK and dV; one wave owns 16 keys, queries stream through LDS
 // =====================================================================================================
-template <typename T, int D>
+template <typename T, int D, bool E32>
 DEVFN void attn_bwd_dkv_body(const gstvd_attn_t& a, const int bx, char* smem) {
   constexpr bool BF = Img<T, D>::BF;
   constexpr int IB = Img<T, D>::BYTES;
+  constexpr int TP = D <= 64 ? 2 : 1;                         // 16-query tiles per inner iteration
   char* sQr = smem;
   char* sQt = BF ? smem + IB : smem;
   char* sOr = smem + (BF ? 2 : 1) * IB;                       // dO row image
@@ -385,10 +508,16 @@ DEVFN void attn_bwd_dkv_body(const gstvd_attn_t& a, const int bx, char* smem) {
   kf.load(Kb + (int64_t)key * a.ldk, kv, g);
   vf.load(Vb + (int64_t)key * a.ldv, kv, g);
   const bool kmasked = kv && a.key_mask != nullptr && a.key_mask[(int64_t)b * a.Lk + key] == 0.f;
+  const float kadd = kv ? (kmasked ? a.mask_neg : 0.f) : -INFINITY;      // additive term of this lane's key (-inf: past the end => p = 0)
   const DropKey dk = make_drop(a.dropout_p, a.site, a.rng);
   const int Lkp = round4(a.Lk);
-  const uint64_t erow = (uint64_t)(b * a.nh + h) * a.Lq;
   const int64_t stat0 = ((int64_t)b * a.nh + h) * a.Lq;
+  // pair index (element index >> 1) of (query 4g of the chunk at c0 = 0, this lane's key); Lkp is even, so a step of one query
+  // is a step of Lkp / 2 pairs.  The two keys of a pair sit in neighbouring lanes (li, li ^ 1): the even lane draws for rows
+  // r = 0, 1 of a tile, the odd lane for rows 2, 3, and one quad permute hands each its partner's draws.
+  const uint64_t half = (uint64_t)(Lkp >> 1);
+  const uint64_t e2lane = ((uint64_t)stat0 + (uint64_t)(4 * g)) * half + (uint64_t)(key >> 1);        // not clamped for keys past the end: the partner lane may be a valid key and takes our draws
+  const bool odd = (key & 1) != 0;
 
   f32x4 accK[D / 16], accV[D / 16];
 #pragma unroll
@@ -431,22 +560,57 @@ DEVFN void attn_bwd_dkv_body(const gstvd_attn_t& a, const int bx, char* smem) {
     __syncthreads();
     if (c0 + 64 < a.Lq) prefetch(c0 + 64);
     const int ntile = (a.Lq - c0 + 15) / 16 < 4 ? (a.Lq - c0 + 15) / 16 : 4;
-    for (int t = 0; t < ntile; ++t) {
-      const f32x4 s = first_product<T, D>(sQr, t * 16, kf, lane);     // [q = 4g+r][key = li]
-      const f32x4 dp = first_product<T, D>(sOr, t * 16, vf, lane);
-      float pd[4], ds[4];
+    const uint64_t e2chunk = e2lane + (uint64_t)c0 * half;
+#pragma unroll 1
+    for (int pr = 0; pr < 4 / TP; ++pr) {
+      const int nt = ntile - TP * pr;
+      if (nt <= 0) break;
+      f32x4 s[TP], dp[TP];
+      float pd[TP][4], ds[TP][4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ql = t * 16 + 4 * g + r, qq = c0 + ql;
-        const bool masked = kmasked || (a.causal && key > qq);
-        const float val = kv ? s[r] * a.scale + (masked ? a.mask_neg : 0.f) : -INFINITY;
-        const float p = __expf(val - sLse[ql]);
-        const float f = drop_factor(dk, (erow + (uint64_t)(qq < a.Lq ? qq : 0)) * (uint64_t)Lkp + (uint64_t)(kv ? key : 0));
-        pd[r] = p * f;
-        ds[r] = p * (dp[r] * f - sDel[ql]) * a.scale;
+      for (int tt = 0; tt < TP; ++tt) {
+        if (tt < nt) {
+          s[tt] = first_product<T, D>(sQr, 16 * TP * pr + tt * 16, kf, lane);     // [q = 4g+r][key = li]
+          dp[tt] = first_product<T, D>(sOr, 16 * TP * pr + tt * 16, vf, lane);
+        }
       }
-      second_product<T, D>(accV, sOt, t * 16, pd, lane);
-      second_product<T, D>(accK, sQt, t * 16, ds, lane);
+#pragma unroll
+      for (int tt = 0; tt < TP; ++tt) {
+        if (tt < nt) {
+          const int q0 = 16 * TP * pr + tt * 16;
+          const f32x4 lse4 = *(const f32x4*)(sLse + q0 + 4 * g);
+          const f32x4 del4 = *(const f32x4*)(sDel + q0 + 4 * g);
+          float f[4] = {1.f, 1.f, 1.f, 1.f};
+          if (dk.on) {
+            const int r0 = odd ? 2 : 0;
+            const uint32_t mine0 = draw_pair<E32>(dk, e2chunk + (uint64_t)(q0 + r0) * half);
+            const uint32_t mine1 = draw_pair<E32>(dk, e2chunk + (uint64_t)(q0 + r0 + 1) * half);
+            const uint32_t other0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine0, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+            const uint32_t other1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine1, 0xB1, 0xf, 0xf, true);
+            const uint32_t d0 = odd ? other0 : mine0, d1 = odd ? other1 : mine1, d2 = odd ? mine0 : other0, d3 = odd ? mine1 : other1;
+            const uint32_t sh = odd ? 16u : 0u;
+            f[0] = ((d0 >> sh) & 0xffffu) >= dk.thr ? dk.scale : 0.f;
+            f[1] = ((d1 >> sh) & 0xffffu) >= dk.thr ? dk.scale : 0.f;
+            f[2] = ((d2 >> sh) & 0xffffu) >= dk.thr ? dk.scale : 0.f;
+            f[3] = ((d3 >> sh) & 0xffffu) >= dk.thr ? dk.scale : 0.f;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float add = kadd;
+            if (a.causal && key > c0 + q0 + 4 * g + r && add == 0.f) add = a.mask_neg;
+            const float p = __expf(s[tt][r] * a.scale + add - lse4[r]);
+            pd[tt][r] = p * f[r];
+            ds[tt][r] = p * (dp[tt][r] * f[r] - del4[r]) * a.scale;
+          }
+        }
+      }
+      if (TP > 1 && nt > 1) {
+        second_product_pair<T, D>(accV, sOt, 16 * TP * pr, pd[0], pd[TP - 1], lane);
+        second_product_pair<T, D>(accK, sQt, 16 * TP * pr, ds[0], ds[TP - 1], lane);
+      } else {
+        second_product<T, D>(accV, sOt, 16 * TP * pr, pd[0], lane);
+        second_product<T, D>(accK, sQt, 16 * TP * pr, ds[0], lane);
+      }
     }
   }
   if (kv) {
@@ -495,11 +659,18 @@ template <typename T, int D> static int attn_fwd_launch(const gstvd_attn_t& a, h
 // One launch for the whole backward: blocks [0, nkb) own 64 keys each (dK, dV), blocks [nkb, nkb + nqb) own 64 queries each (dQ).
 // The dK/dV blocks come first: they are the longer ones (two second products per tile).
 template <typename T, int D>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(gstvd_attn_t a, int nkb) {
+__global__ __launch_bounds__(256, (D <= 64 ? 3 : 2)) void attn_bwd_kernel(gstvd_attn_t a, int nkb) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int bx = blockIdx.x;
-  if (bx < nkb) attn_bwd_dkv_body<T, D>(a, bx, smem);
-  else attn_bwd_dq_body<T, D>(a, bx - nkb, smem);
+  if constexpr (sizeof(T) == 2) {
+    if (attn_small_index_space(a)) {
+      if (bx < nkb) attn_bwd_dkv_body<T, D, true>(a, bx, smem);
+      else attn_bwd_dq_body<T, D, true>(a, bx - nkb, smem);
+      return;
+    }
+  }
+  if (bx < nkb) attn_bwd_dkv_body<T, D, false>(a, bx, smem);
+  else attn_bwd_dq_body<T, D, false>(a, bx - nkb, smem);
 }
 
 template <typename T, int D> static int attn_bwd_launch(const gstvd_attn_t& a, hipStream_t s) {

@@ -40,6 +40,7 @@ class BackwardPipeline(object):
         self._bufs, self.comm, self.tail_event = {}, None, None
         import os
         self.use_comm_stream = os.environ.get("GSTVD_PIPE_COMM", "1") != "0"
+        self.update_stream = os.environ.get("GSTVD_PIPE_UPDATE_STREAM", "0") != "0"
         if optimizer is not None:
             optimizer.grad_scale = 1.0 / self.world
         engine.pipe = self
@@ -73,7 +74,20 @@ class BackwardPipeline(object):
         self.slices.append((lo, hi))
         sl = flat.G[lo:hi]
         if not self.collective:
-            self._update(lo, hi, None)
+            if self.update_stream and sl.is_cuda and self.opt is not None:
+                # N = 1: the slice's AdamW (HBM-bound) moves to its own stream so that it runs beside the NEXT slice's
+                # weight-gradient GEMMs (MFMA-bound) and the rest of backward instead of in front of them on the aux stream
+                if self.comm is None:
+                    self.comm = torch.cuda.Stream(device=sl.device)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                self.comm.wait_event(ev)
+                with torch.cuda.stream(self.comm):
+                    self._update(lo, hi, None)
+                    self.tail_event = torch.cuda.Event()
+                    self.tail_event.record(self.comm)
+            else:
+                self._update(lo, hi, None)
         elif not sl.is_cuda or not self.use_comm_stream:       # host tensors (gloo tests) / in-line variant
             reduced = None
             if self.compress == "bf16":
