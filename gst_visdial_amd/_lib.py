@@ -55,6 +55,11 @@ class AttnDesc(C.Structure):
                 ("q_bstride", _i32), ("kv_bstride", _i32)]
 
 
+class SampleDesc(C.Structure):
+    _fields_ = [("logits", _vp), ("ld", _i64), ("dtype", _i32), ("B", _i32), ("V", _i32), ("top_k", _i32), ("temperature", _f32),
+                ("u", _vp), ("out", _vp), ("out_stride", _i64), ("banned", _vp), ("banned_ld", _i64)]
+
+
 class ColsumEntry(C.Structure):
     _fields_ = [("partial", _vp), ("out", _vp * 3), ("nblk", _i64), ("stride", _i64), ("H", _i64),
                 ("nvec", _i32), ("accumulate", _i32 * 3), ("blk0", _i32)]
@@ -92,6 +97,7 @@ SIGNATURES = {
     "gstvd_ce_fwd": (_i32, [_vp, _i64, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
     "gstvd_ce_bwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _i32, _vp, _i64, _vp]),
     "gstvd_answer_scores": (_i32, [_vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _vp]),
+    "gstvd_sample_topk": (_i32, [C.POINTER(SampleDesc), _vp]),
     "gstvd_vl_split": (_i32, [_vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _f32, _u32, _u32, _vp, _vp]),
     "gstvd_cast": (_i32, [_vp, _i32, _vp, _i32, _i64, _vp]),
     "gstvd_scale": (_i32, [_vp, _vp, _i64, _vp]),

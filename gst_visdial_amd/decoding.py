@@ -25,31 +25,42 @@ def batch_top_k_top_p_sampling(logits, top_k=0, top_p=0.0, filter_value=NEG_INF)
     return logits
 
 
-def batch_ngram_blocking(logits, enc_input_ids, dec_input_ids, ngram_size=0, filter_value=NEG_INF,
-                         special_token_ids=(0, 100, 101, 102, 103)):
-    """Ban every token that would complete an n-gram already present in `enc_input_ids` (n-grams that touch a
-    special token are ignored).  Vectorised on the logits' device -- no host round trip per decode step; same bans as
-    the reference's per-row dictionary loops (`_ngram_blocking_loop` below restates those, tests compare the two)."""
-    assert logits.dim() == 2
+def ngram_banned_mask(enc_input_ids, dec_input_ids, ngram_size, vocab, device=None, special_token_ids=(0, 100, 101, 102, 103)):
+    """bool [B, vocab + 1] (column `vocab` is a dummy): True for every token that would complete an n-gram already present in
+    `enc_input_ids` (n-grams that touch a special token are ignored) -- or None when nothing can be banned.  Vectorised on the
+    device, free of host synchronisation (scatter instead of boolean-mask indexing, scalar compares instead of an uploaded
+    table): capturable into a hipGraph; same bans as the reference's per-row dictionary loops (`_ngram_blocking_loop`)."""
     cur = dec_input_ids.shape[-1]
     T = enc_input_ids.shape[-1]
     n = ngram_size
     if n <= 0 or cur < n - 1 or T < n:      # (python slice semantics of the reference: a short prefix never matches)
-        return logits
-    dev = logits.device
+        return None
+    dev = device if device is not None else enc_input_ids.device
     hist = enc_input_ids.to(dev)
     win = hist.unfold(1, n, 1)                                              # [B, T-n+1, n] every n-gram of the history
-    special = torch.tensor(special_token_ids, device=dev, dtype=hist.dtype)
-    clean = ~(win.unsqueeze(-1) == special).any(-1).any(-1)                 # n-grams without a special token
+    bad = torch.zeros_like(win, dtype=torch.bool)
+    for sid in special_token_ids:
+        bad |= win == sid
+    clean = ~bad.any(-1)                                                    # n-grams without a special token
     if n > 1:
         prefix = dec_input_ids.to(dev)[:, cur - (n - 1):cur]                # the last n-1 generated tokens
         hit = (win[..., :n - 1] == prefix[:, None, :]).all(-1) & clean
     else:
         hit = clean
-    rows = torch.arange(hist.shape[0], device=dev)[:, None].expand_as(hit)
-    banned = torch.zeros_like(logits, dtype=torch.bool)
-    banned[rows[hit], win[..., n - 1][hit]] = True
-    return logits.masked_fill(banned, filter_value)
+    last_tok = win[..., n - 1]
+    idx = torch.where(hit, last_tok, torch.full_like(last_tok, vocab))      # n-grams that do not hit point at the dummy column
+    return torch.zeros(hist.shape[0], vocab + 1, dtype=torch.bool, device=dev).scatter_(1, idx, True)
+
+
+def batch_ngram_blocking(logits, enc_input_ids, dec_input_ids, ngram_size=0, filter_value=NEG_INF,
+                         special_token_ids=(0, 100, 101, 102, 103)):
+    """utils/decoding_utils.py:34-77 on the logits' device (see `ngram_banned_mask`)."""
+    assert logits.dim() == 2
+    V = logits.shape[-1]
+    banned = ngram_banned_mask(enc_input_ids, dec_input_ids, ngram_size, V, logits.device, special_token_ids)
+    if banned is None:
+        return logits
+    return logits.masked_fill(banned[:, :V], filter_value)
 
 
 def _ngram_blocking_loop(logits, enc_input_ids, dec_input_ids, ngram_size=0, filter_value=NEG_INF,

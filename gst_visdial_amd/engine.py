@@ -951,36 +951,63 @@ class Engine(object):
 
         return encode, one_token, st
 
-    def _decode_session(self, ins, L0, max_seq_len):
-        """hipGraph form of a decode call (generate.py's loop calls sample() with the same shapes batch after batch):
-        static copies of the inputs, one captured graph for `encode`, one per decoder position for `one_token`.
-        Returns (refresh(ins), run_encode(), run_token(tok, t) -> logits)."""
+    @staticmethod
+    def _fused_sampling(P):
+        """The fused sampling kernel covers the reference's settings (generate.py:138-141,177-180: top_k 7, top_p 0); top-p or
+        a very wide top-k take the torch-op form of the filters, issued eagerly step by step (no captured token graph)."""
+        return P["top_p"] <= 0.0 and P["top_k"] <= ops.SAMPLE_MAX_TOP_K
+
+    @staticmethod
+    def _sampling_step(logits, cur, pos, hist, P, u_row):
+        """One step of models/visual_dialog_model.py:96-108 on static buffers: cur[:, pos] <- the token drawn from `logits`
+        (temperature, n-gram ban against `hist`, top-k / top-p, softmax, inverse-CDF draw from the uniforms `u_row`).
+        Free of host synchronisation and of generator state, so the token graph captures it together with the decoder stack."""
+        from . import decoding
+        if Engine._fused_sampling(P):
+            banned = decoding.ngram_banned_mask(hist, cur[:, :pos], P["ngram"], logits.shape[-1], logits.device)
+            ops.sample_topk(logits, P["temperature"], P["top_k"], u_row, cur[:, pos], banned)
+            return
+        last = logits / P["temperature"]
+        last = decoding.batch_ngram_blocking(last, hist, cur[:, :pos], ngram_size=P["ngram"])
+        last = decoding.batch_top_k_top_p_sampling(last, top_k=P["top_k"], top_p=P["top_p"])
+        prob = torch.softmax(last, dim=-1)
+        cur[:, pos] = decoding.draw_from_uniform(prob, u_row).view(-1)
+
+    def _decode_session(self, ins, L0, max_seq_len, P):
+        """hipGraph form of a decode call (generate.py's loop calls sample() with the same shapes and settings batch after
+        batch): static copies of the inputs, one captured graph for `encode` and ONE for the whole token loop -- every decoder
+        position's stack AND its sampling step (filters, softmax, draw, append), so that nothing of the loop is issued from
+        the host at replay (round 1-2 replayed one graph per position and ran ~25 small torch kernels per step eagerly in
+        between: the loop was bound by host issue).
+        Returns (refresh(ins, uniforms), run_encode(), run_tokens(), st, cur, last_logits)."""
         static = tuple(x.clone() if x is not None else None for x in ins)
-        tok_buf = torch.zeros(ins[3].shape[0], dtype=torch.long, device=ins[3].device)
+        ids, segs, dec_ids = static[3], static[4], static[6]
+        Bn, dev = ids.shape[0], ids.device
+        steps = L0 + max_seq_len - 1
+        cur = torch.zeros(Bn, L0 + max_seq_len, dtype=torch.long, device=dev)
+        u_buf = torch.zeros(max_seq_len, Bn, dtype=torch.float32, device=dev)
         encode, one_token, st = self._decode_plan(static, L0, max_seq_len)
         from .graph import capture, gc_quiet
         with gc_quiet():
             g_enc = torch.cuda.CUDAGraph()
             with capture(g_enc):
                 encode()
-            graphs, outs = [], []
-            for t in range(L0 + max_seq_len - 1):
-                g = torch.cuda.CUDAGraph()
-                with capture(g, pool=g_enc.pool(), quiesce=False):
-                    outs.append(one_token(tok_buf, t))
-                graphs.append(g)
+                hist = ids * (segs == 0).long()
+            g_dec = torch.cuda.CUDAGraph()
+            with capture(g_dec, pool=g_enc.pool(), quiesce=False):
+                cur[:, :L0] = dec_ids
+                for t in range(steps):
+                    logits = one_token(cur[:, t], t)
+                    if t >= L0 - 1:
+                        self._sampling_step(logits, cur, t + 1, hist, P, u_buf[t - (L0 - 1)])
 
-        def refresh(new):
+        def refresh(new, uniforms):
             for dst, src in zip(static, new):
                 if dst is not None:
                     dst.copy_(src)
+            u_buf.copy_(uniforms)
 
-        def run_token(tok, t):
-            tok_buf.copy_(tok)
-            graphs[t].replay()
-            return outs[t]
-
-        return refresh, g_enc.replay, run_token, st
+        return refresh, g_enc.replay, g_dec.replay, st, cur, logits
 
     @torch.no_grad()
     def sample(self, feats, loc, img_mask, ids, segs, att_mask, dec_ids, temperature=1.0, top_k=0, top_p=0.0,
@@ -990,53 +1017,60 @@ class Engine(object):
         the cross-attention K/V of all 37+T encoder states in all 12 layers at every step (use_cache=False); here the
         encoder, VLFusion and the cross K/V projection run once, and each step feeds ONE token per row through the stack,
         appending its self-attention K/V to a [B, Umax, H] cache per layer.  Same arithmetic, O(U) instead of O(U^2).
-        From the second call with the same shapes on (params['amd_decode_graph'], default on) the device work is replayed
-        from captured hipGraphs (one for the encoder side, one per decoder position): ~2500 launches per call leave the host.
-        Token-id work (filters, n-gram ban, EOS fill) is integer-exact torch / host plumbing (decoding.py).
-        `uniforms` [max_seq_len, B] in (0, 1): draw token t by inverse CDF from uniforms[t] on the device instead of
-        torch.multinomial (whose stream is device specific) -- the same rule the oracle applies to the reference, so sampled
-        ids can be compared under real sampling."""
+        From the second call with the same shapes and sampling settings on (params['amd_decode_graph'], default on) the
+        device work is replayed from two captured hipGraphs (the encoder side; the whole token loop incl. its sampling
+        steps): ~3000 launches per call leave the host.
+        Token-id work (filters, n-gram ban, EOS fill) is integer-exact torch index plumbing (decoding.py), free of host syncs.
+        Token t is drawn by inverse CDF from uniforms[t] ([max_seq_len, B] in (0, 1); drawn from torch's default generator when
+        the caller passes none) instead of torch.multinomial (whose stream is device specific) -- the same rule the oracle
+        applies to the reference, so sampled ids can be compared under real sampling."""
         from . import decoding
         dc = self.dec_cfg
         if segs is None:
             segs = torch.zeros_like(ids)
         ins = (feats, loc, img_mask, ids, segs, att_mask, dec_ids)
         L0 = dec_ids.shape[1]
-        sig = (L0, max_seq_len) + tuple((tuple(x.shape), x.dtype) if x is not None else None for x in ins)
-        use_graph = bool(self.model.params.get("amd_decode_graph", True))
+        Bn = ids.shape[0]
+        P = dict(temperature=float(temperature), top_k=int(top_k), top_p=float(top_p), ngram=int(ngram_blocking_size))
+        sig = (L0, max_seq_len, tuple(sorted(P.items()))) + tuple((tuple(x.shape), x.dtype) if x is not None else None for x in ins)
+        if uniforms is None:
+            # the call's randomness, drawn ONCE from torch's default CUDA generator (eagerly: no generator state inside the
+            # captured graphs); every step then draws by inverse CDF -- the same distribution as the reference's
+            # torch.multinomial (whose stream is device specific anyway), and the same ids from eager issue and graph replay
+            u = torch.rand(max_seq_len, Bn, device=ids.device, dtype=torch.float32).clamp_min_(1e-12)
+        else:
+            u = uniforms.to(ids.device, torch.float32).contiguous()
+        use_graph = bool(self.model.params.get("amd_decode_graph", True)) and self._fused_sampling(P)
         # parameters edited since the last call (load_state_dict, an optimizer step): the captured graphs read the flat
         # buffers / bf16 shadow, so bring those up to date OUTSIDE the graphs; a re-materialised buffer drops the sessions
         self.prepare(ids.device)
         sess = self._decode_sessions.get(sig) if use_graph else None
         if sess is not None:
-            refresh, run_encode, run_token, dst = sess
-            refresh(ins)
+            refresh, run_encode, run_tokens, dst, cur, last_logits = sess
+            refresh(ins, u)
+            run_encode()
+            run_tokens()
+            cur, logits = cur.clone(), last_logits
         else:
-            run_encode, run_token, dst = self._decode_plan(ins, L0, max_seq_len)
-        run_encode()
-        hist = ids * (segs == 0).long()
-        cur, seq = dec_ids, []
-        for t in range(L0 + max_seq_len - 1):
-            logits = run_token(cur[:, t], t)
-            if t < L0 - 1:
-                continue                                   # still consuming the given prefix
-            last = logits / temperature
-            last = decoding.batch_ngram_blocking(last, hist, cur, ngram_size=ngram_blocking_size)
-            last = decoding.batch_top_k_top_p_sampling(last, top_k=top_k, top_p=top_p)
-            prob = torch.softmax(last, dim=-1)
-            nxt = torch.multinomial(prob, 1) if uniforms is None else decoding.draw_from_uniform(prob, uniforms[len(seq)])
-            cur = torch.cat((cur, nxt), dim=-1)
-            seq.append(nxt)
+            run_encode, one_token, dst = self._decode_plan(ins, L0, max_seq_len)
+            run_encode()
+            hist = ids * (segs == 0).long()
+            cur = torch.zeros(Bn, L0 + max_seq_len, dtype=torch.long, device=ids.device)
+            cur[:, :L0] = dec_ids
+            for t in range(L0 + max_seq_len - 1):
+                logits = one_token(cur[:, t], t)
+                if t >= L0 - 1:                            # (earlier positions only consume the given prefix)
+                    self._sampling_step(logits, cur, t + 1, hist, P, u[t - (L0 - 1)])
         self.last = dict(decode_logits=logits)            # last position's raw logits (tests / debugging)
         # the encoder side of this call (cross-attention K/V of all layers, masks) stays valid in the arena until the next
         # engine call: `rescore_sampled` scores the sampled answer against it without a second encoder pass
-        out = decoding.pad_after_eos(torch.cat(seq, 1), dc.eos_token_id, dc.pad_token_id)
+        out = decoding.pad_after_eos(cur[:, L0:], dc.eos_token_id, dc.pad_token_id)
         if use_graph and sess is None:
             # first call with these shapes ran eagerly (it also initialised every lazily built table / attribute / arena
             # chunk); capture now so the next batch replays
             if len(self._decode_sessions) >= 4:
                 self._decode_sessions.clear()
-            self._decode_sessions[sig] = self._decode_session(ins, L0, max_seq_len)
+            self._decode_sessions[sig] = self._decode_session(ins, L0, max_seq_len, P)
         # (after the capture: capturing runs the Python side of encode() again -- which rewinds the arena bookkeeping and drops
         # this marker -- but executes nothing, so the eager call's encoder states are still what the arena holds)
         self._last_decode = (dst, ids.shape[0], self.arena)

@@ -491,6 +491,29 @@ def ce_bwd(logits, labels, lse, stats, gscale, mean, M, V, dlogits, ignore_index
                                              _stream()))
 
 
+SAMPLE_MAX_TOP_K = 64      # beyond this (or with top-p) the filter runs as torch ops (decoding.batch_top_k_top_p_sampling)
+
+
+def sample_topk(logits, temperature, top_k, u, out, banned=None):
+    """One sampling step (gstvd_sample_topk): out[b] <- inverse-CDF draw from softmax(top_k(logits / temperature, banned -> -inf)).
+    logits [B, V] fp32 / bf16 (row stride free); u [B] fp32 in (0, 1); out: int64 view with B elements (any stride, e.g. a
+    column of the id buffer); banned: None or bool / uint8 [B, >= V]."""
+    lib = L.load()
+    Bn, V = logits.shape
+    d = L.SampleDesc()
+    d.logits, d.ld, d.dtype, d.B, d.V, d.top_k, d.temperature = _p(logits), logits.stride(0), dt(logits), Bn, V, int(top_k), float(temperature)
+    if u.dtype != torch.float32 or not u.is_contiguous() or u.numel() != Bn:
+        raise L.GstvdError("sample_topk: u must be a contiguous fp32 vector of B uniforms")
+    if out.dtype != torch.int64 or out.numel() != Bn or logits.stride(1) != 1:
+        raise L.GstvdError("sample_topk: out must hold B int64 ids; logits rows must be dense")
+    d.u, d.out, d.out_stride = _p(u), _p(out), (out.stride(0) if out.dim() else 1)
+    if banned is not None:
+        if banned.dtype not in (torch.bool, torch.uint8) or banned.stride(1) != 1 or banned.shape[1] < V:
+            raise L.GstvdError("sample_topk: banned must be bool / uint8 [B, >= V] with dense rows")
+        d.banned, d.banned_ld = _p(banned), banned.stride(0)
+    L.check("gstvd_sample_topk", lib.gstvd_sample_topk(C.byref(d), _stream()))
+
+
 def answer_scores(logits, lse, dec_ids, rows, U, scores):
     lib = L.load()
     L.check("gstvd_answer_scores", lib.gstvd_answer_scores(_p(logits), logits.stride(-2), _p(lse), _p(dec_ids), rows, U,

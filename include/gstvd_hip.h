@@ -213,6 +213,17 @@ int gstvd_ce_bwd(const void* logits, int64_t ldl, const int64_t* labels, const f
 int gstvd_answer_scores(const void* logits, int64_t ldl, const float* lse, const int64_t* dec_ids,
                         int64_t rows, int64_t U, int32_t dtype, float* scores, gstvd_stream_t s);
 
+/* One sampling step of the decode loop (models/visual_dialog_model.py:96-108 after the n-gram filter has produced `banned`;
+ * utils/decoding_utils.py:4-35 for the top-k rule): z = logits / temperature (banned -> -inf); top_k > 0: z below the k-th
+ * largest z -> -inf (ties with it stay); out[b * out_stride] = first index whose cumulative softmax probability reaches
+ * u[b] * total (inverse CDF -- the draw the oracle substitutes for the reference's torch.multinomial, whose stream is device
+ * specific).  logits [B, ld >= V] fp32 or bf16; banned: NULL or uint8 [B, banned_ld >= V]; u [B] in (0, 1). */
+typedef struct {
+  const void* logits; int64_t ld; int32_t dtype; int32_t B; int32_t V; int32_t top_k; float temperature;
+  const float* u; int64_t* out; int64_t out_stride; const uint8_t* banned; int64_t banned_ld;
+} gstvd_sample_t;
+int gstvd_sample_topk(const gstvd_sample_t* a, gstvd_stream_t s);
+
 /* backward of VLFusion's concat + dropout (visual_dialog_model.py:132-133): d_enc [B, R+T, H] ->
  * d_v [B*R, H] (vision rows first) and d_t [B*T, H], each multiplied by the dropout mask its forward GEMM
  * epilogue applied (element index (b*R + r)*H + n under site_v, (b*T + t)*H + n under site_t). */

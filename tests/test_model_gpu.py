@@ -156,28 +156,30 @@ def test_grad_accumulation_matches_two_backwards():
     assert maxerr(model.encoder.bert_pretrained.bert.embeddings.word_embeddings.weight.grad, 2 * e1) < 1e-6 + 1e-5 * e1.abs().max().item()
 
 
-def test_sampling_decode_matches_reference_argmax_path(monkeypatch):
+def test_sampling_decode_matches_reference_argmax_path():
     s = sc()
     model, params, cfg = s.build_tiny_model("fp32", DEV, mode="vd_gen_val")
     model.eval()
     g, d = load_npz("tiny_train.npz"), load_npz("tiny_decode.npz")
-    monkeypatch.setattr(torch, "multinomial", lambda prob, n, **kw: prob.argmax(-1, keepdim=True))
+    # the golden trace was recorded with the reference's torch.multinomial replaced by argmax (top_k 7): after the n-gram
+    # ban that is the single survivor of top_k = 1, whatever the uniforms -- drawn by the engine's own sampling kernel
     kw = s.golden_batch(g, DEV)
     kw["dec_input_ids"] = torch.full((kw["enc_input_ids"].shape[0], 1), 101, dtype=torch.long, device=DEV)
     kw["dec_labels"] = None
-    seq = model(temperature=0.7, top_k=7, top_p=0.0, ngram_blocking_size=2, **kw)
+    seq = model(temperature=0.7, top_k=1, top_p=0.0, ngram_blocking_size=2, **kw)
     assert seq.shape == d["sequence"].shape
     assert torch.equal(seq.cpu(), d["sequence"])
 
 
 @pytest.mark.isolated
-def test_graph_captured_decode_equals_eager_decode(monkeypatch):
+def test_graph_captured_decode_equals_eager_decode():
     """generate.py calls the decode branch batch after batch with the same shapes: from the second call on the device
-    work is replayed from hipGraphs (encoder side + one graph per decoder position).  Same token ids as the eager path,
+    work is replayed from hipGraphs (encoder side + the whole token loop incl. sampling).  Same token ids as the eager path,
     also for new inputs copied into the captured buffers, and still the reference's golden sequence."""
     s = sc()
     g, d = load_npz("tiny_train.npz"), load_npz("tiny_decode.npz")
-    monkeypatch.setattr(torch, "multinomial", lambda prob, n, **kw: prob.argmax(-1, keepdim=True))
+    # the golden trace was recorded with the reference's torch.multinomial replaced by argmax (top_k 7): after the n-gram
+    # ban that is the single survivor of top_k = 1, whatever the uniforms -- drawn by the engine's own sampling kernel
 
     def batch(shift):
         kw = s.golden_batch(g, DEV)
@@ -189,32 +191,32 @@ def test_graph_captured_decode_equals_eager_decode(monkeypatch):
             kw["enc_image_features"] = kw["enc_image_features"].flip(0).contiguous()
         return kw
 
-    args = dict(temperature=0.7, top_k=7, top_p=0.0, ngram_blocking_size=2)
+    args = dict(temperature=0.7, top_k=1, top_p=0.0, ngram_blocking_size=2)
     model, params, cfg = s.build_tiny_model("fp32", DEV, mode="vd_gen_val")
     model.eval()
     a0 = model(**args, **batch(0))                             # eager, then captures
     assert len(model.engine._decode_sessions) == 1
     a1 = model(**args, **batch(0))                             # replay
     assert torch.equal(a0.cpu(), d["sequence"]) and torch.equal(a1, a0)
-    # real multinomial draws at high temperature: the drawn ids follow the probabilities to the last bit, so equality with
+    # real draws at high temperature: the drawn ids follow the probabilities to the last bit, so equality with
     # the eager engine needs bit-identical logits at every step, and different inputs give different sequences
-    monkeypatch.undo()
     hot = dict(temperature=2.0, top_k=60, top_p=0.0, ngram_blocking_size=0)
     ref, rparams, _ = s.build_tiny_model("fp32", DEV, mode="vd_gen_val")
     rparams["amd_decode_graph"] = False
     ref.eval()
     outs = []
-    for shift in (0, 17):
+    for shift in (0, 17, 5):
         torch.manual_seed(99)
-        a = model(**hot, **batch(shift))                       # replay (same shapes as the captured session)
+        a = model(**hot, **batch(shift))                       # new settings: eager + capture first, then two replays
         torch.manual_seed(99)
         r = ref(**hot, **batch(shift))                         # eager engine
         assert torch.equal(a, r)
         la, lr = model.engine.last["decode_logits"].clone(), ref.engine.last["decode_logits"].clone()
         assert torch.equal(la, lr)                             # bit-identical logits from the replayed graphs
         outs.append(la)
-    assert len(model.engine._decode_sessions) == 1 and len(ref.engine._decode_sessions) == 0
-    assert not torch.equal(outs[0], outs[1])                   # ... and they do follow the refreshed inputs
+    # one session per (shapes, sampling settings): the token graph contains the sampling steps
+    assert len(model.engine._decode_sessions) == 2 and len(ref.engine._decode_sessions) == 0
+    assert not torch.equal(outs[1], outs[2])                   # ... and they do follow the refreshed inputs
 
 
 def test_smoke_entry_point():

@@ -490,6 +490,46 @@ def test_gemm_grouped_column_sums():
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("V", [97, 30522])
+def test_sample_topk_matches_the_torch_filters_and_inverse_cdf(dtype, V):
+    """gstvd_sample_topk vs the torch-op form of the same step (decoding.py: temperature, ban, top-k with ties, softmax,
+    inverse-CDF draw): same ids, except where a uniform falls within rounding distance of a CDF step."""
+    from gst_visdial_amd import decoding
+    o = ops()
+    Bn = 16
+    g = torch.Generator().manual_seed(V)
+    for case, (top_k, temp, with_ban) in enumerate([(0, 1.0, False), (1, 0.7, True), (7, 0.7, False), (7, 0.7, True), (40, 1.3, True), (64, 2.0, False)]):
+        logits = (torch.randn(Bn, V, generator=g) * 2.5).to(DEV).to(dtype)
+        logits[:, ::3] = (logits[:, ::3].float() * 4).round().div(4).to(dtype)      # plenty of exact ties
+        logits[1, :] = logits[1, 0]                                                  # a constant row: every token ties
+        banned = None
+        if with_ban:
+            banned = torch.zeros(Bn, V + 1, dtype=torch.bool, device=DEV)
+            banned[:, torch.randint(0, V, (V // 5,), generator=g).to(DEV)] = True
+            banned[2, logits[2].float().argmax()] = True                            # the best token of a row is banned
+        u = torch.rand(Bn, generator=g).clamp_min(1e-6).to(DEV)
+        ids = torch.full((Bn, 3), -1, dtype=torch.long, device=DEV)
+        o.sample_topk(logits, temp, top_k, u, ids[:, 1], banned)
+        z = logits.float() / temp
+        if banned is not None:
+            z = z.masked_fill(banned[:, :V], float("-inf"))
+        z = decoding.batch_top_k_top_p_sampling(z, top_k=top_k, top_p=0.0)
+        prob = torch.softmax(z.double(), -1)
+        want = decoding.draw_from_uniform(prob.float(), u).view(-1)
+        got = ids[:, 1]
+        assert (ids[:, 0] == -1).all() and (ids[:, 2] == -1).all()                   # strided output: neighbours untouched
+        assert ((got >= 0) & (got < V)).all()
+        assert (prob.gather(1, got[:, None]) > 0).all(), case                        # never a filtered / banned token
+        c = torch.cumsum(prob, -1)
+        for b in (got != want).nonzero().view(-1).tolist():
+            lo, hi = sorted((int(got[b]), int(want[b])))
+            # a disagreement is legitimate only when u sits on a CDF step: the mass strictly between the two picks is ~0
+            assert abs(float(c[b, hi - 1] - c[b, lo]) if hi - 1 >= lo else 0.0) < 1e-5 and \
+                min(abs(float(c[b, lo]) - float(u[b])), abs(float(c[b, hi - 1]) - float(u[b]))) < 1e-5, (case, b)
+        assert (got != want).sum().item() <= 1, case
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_attention_kv_cache_strides_and_shared_kv(dtype):
     """Forward-only descriptor extras: Lq = 1 against a partially filled [B, Umax, H] cache (kv_bstride) and K/V shared
     by groups of batch rows (kv_group)."""

