@@ -24,6 +24,7 @@
 //   * fp32 parity mode runs the same skeleton on v_mfma_f32_16x16x4_f32.
 #include "common.h"
 #include <math.h>
+#include <type_traits>
 
 template <typename T, int D> struct Img {
   static constexpr bool BF = sizeof(T) == 2;
@@ -206,26 +207,6 @@ DEVFN void second_product_pair(f32x4 (&acc)[D / 16], const char* img_tr, int xb,
   }
 }
 
-// Reductions over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48), result in every lane: two gfx950 lane swaps
-// inside the VALU instead of two dependent ds_bpermute round trips (~100 cycles each) through the LDS crossbar.
-//   v_permlane16_swap a, b: rows 1, 3 of a <-> rows 0, 2 of b;   v_permlane32_swap a, b: rows 2, 3 of a <-> rows 0, 1 of b.
-DEVFN void rows_swap16(float& x, float& y) { asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y)); }
-DEVFN void rows_swap32(float& x, float& y) { asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y)); }
-DEVFN float rows_max(float v) {
-  float w = v;
-  rows_swap16(v, w);
-  v = fmaxf(v, w); w = v;
-  rows_swap32(v, w);
-  return fmaxf(v, w);
-}
-DEVFN float rows_sum(float v) {
-  float w = v;
-  rows_swap16(v, w);
-  v += w; w = v;
-  rows_swap32(v, w);
-  return v + w;
-}
-
 // Dropout draws.  E32: the launch has fewer than 2^33 score elements, so the high word of every pair index is zero and its
 // term of drop_draw (a quarter-rate integer multiply per draw) vanishes -- same stream, cheaper arithmetic.
 template <bool E32> DEVFN uint32_t draw_pair(const DropKey& k, uint64_t e2) {
@@ -362,6 +343,115 @@ DEVFN void attn_fwd_body(const gstvd_attn_t& a, char* smem) {
 #pragma unroll
     for (int i = 0; i < D / 16; ++i) st4(Op + i * 16 + 4 * g, accO[i] * inv);
     if (g == 0 && a.LSE) a.LSE[((int64_t)b * a.nh + h) * a.Lq + q] = m_run + __logf(l_tot);
+  }
+}
+
+// =====================================================================================================
+// forward, ONE query per (row, head): the KV-cached decode step (Lq = 1, no dropout)
+// =====================================================================================================
+// The tiled kernel above would run one useful lane per workgroup and walk the keys chunk after chunk (10.6 us for the
+// 293 keys of the cross-attention: five dependent load -> LDS -> compute rounds).  Here the workgroup's 256 threads split the
+// KEYS: groups of lanes score one key each against the query (16-byte pieces of its K row), one block-wide max / sum, then the
+// threads split (key group, output column) for P.V with coalesced V reads, eight loads in flight per thread -- two memory
+// round trips in all, fp32 arithmetic.
+constexpr int DEC_NT = 1024;
+template <typename T, int D>
+__global__ __launch_bounds__(DEC_NT) void attn_decode_kernel(gstvd_attn_t a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sq = (float*)smem;                                   // [D] the query
+  float* sp = sq + D;                                         // [Lk] scores, then probabilities
+  constexpr int NWV = DEC_NT / 64;
+  __shared__ float sred[NWV];
+  __shared__ float sacc[DEC_NT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int bk = a.kv_group > 1 ? b / a.kv_group : b;
+  const int64_t qbs = a.q_bstride > 0 ? a.q_bstride : a.Lq, kbs = a.kv_bstride > 0 ? a.kv_bstride : a.Lk;
+  const T* Qr = (const T*)a.Q + (int64_t)b * qbs * a.ldq + h * D;
+  const T* Kb = (const T*)a.K + (int64_t)bk * kbs * a.ldk + h * D;
+  const T* Vb = (const T*)a.V + (int64_t)bk * kbs * a.ldv + h * D;
+  if (tid < D) sq[tid] = to_f(Qr[tid]);
+  __syncthreads();
+  // scores: PPK lanes share one key (a 16-byte piece of its K row each), a wave scores 64 / PPK keys per round, the four waves
+  // interleave rounds; every lane has one load per round in flight and the rounds are independent (unrolled)
+  constexpr int VE = 16 / sizeof(T), PPK = D / VE, KPW = 64 / PPK;
+  const int kr = lane / PPK, piece = lane % PPK;
+  float qreg[VE];
+#pragma unroll
+  for (int j = 0; j < VE; ++j) qreg[j] = sq[piece * VE + j];
+  float mx = -INFINITY;
+  constexpr int RND = 4;                                      // rounds per iteration: their loads are issued together
+  typedef typename std::conditional<sizeof(T) == 2, bf16x8, f32x4>::type vec_t;
+  for (int k0 = wave * KPW; k0 < a.Lk; k0 += RND * NWV * KPW) {
+    vec_t kv[RND];
+#pragma unroll
+    for (int r = 0; r < RND; ++r) {
+      const int key = k0 + r * NWV * KPW + kr;
+      const int kc = key < a.Lk ? key : a.Lk - 1;             // (clamped: the value is discarded below)
+      kv[r] = *(const vec_t*)(Kb + (int64_t)kc * a.ldk + piece * VE);
+    }
+#pragma unroll
+    for (int r = 0; r < RND; ++r) {
+      const int key = k0 + r * NWV * KPW + kr;
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < VE; ++j) s += (float)kv[r][j] * qreg[j];
+#pragma unroll
+      for (int o = 1; o < PPK; o <<= 1) s += __shfl_xor(s, o, 64);
+      if (key < a.Lk) {
+        const float madd = (a.key_mask == nullptr || a.key_mask[(int64_t)bk * a.Lk + key] != 0.f) ? 0.f : a.mask_neg;
+        s = s * a.scale + madd;
+        if (piece == 0) sp[key] = s;
+        mx = fmaxf(mx, s);
+      }
+    }
+  }
+  mx = wave_max(mx);
+  if (lane == 0) sred[wave] = mx;
+  __syncthreads();
+  mx = sred[0];
+#pragma unroll
+  for (int w = 1; w < NWV; ++w) mx = fmaxf(mx, sred[w]);
+  float sum = 0.f;
+  for (int key = tid; key < a.Lk; key += DEC_NT) {
+    const float pv = __expf(sp[key] - mx);
+    sp[key] = pv;
+    sum += pv;
+  }
+  sum = wave_sum(sum);
+  __syncthreads();                                            // (sred reads above are done; sp[] writes below are visible)
+  if (lane == 0) sred[wave] = sum;
+  __syncthreads();
+  sum = 0.f;
+#pragma unroll
+  for (int w = 0; w < NWV; ++w) sum += sred[w];
+  // P.V: thread = (key group kg, output column dcol); a wave reads 64 consecutive columns of a V row
+  constexpr int NG = DEC_NT / D;                              // key groups: 16 (d = 64), 8 (d = 128), 32 (d = 32)
+  const int dcol = tid % D, kg = tid / D;
+  float acc = 0.f;
+  {
+    constexpr int UN = 4;                                     // four independent V loads in flight per thread
+    float part[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) part[u] = 0.f;
+    int key = kg;
+    for (; key + (UN - 1) * NG < a.Lk; key += UN * NG) {
+#pragma unroll
+      for (int u = 0; u < UN; ++u) part[u] += sp[key + u * NG] * to_f(Vb[(int64_t)(key + u * NG) * a.ldv + dcol]);
+    }
+    for (; key < a.Lk; key += NG) acc += sp[key] * to_f(Vb[(int64_t)key * a.ldv + dcol]);
+#pragma unroll
+    for (int u = 0; u < UN; ++u) acc += part[u];
+  }
+  sacc[tid] = acc;
+  __syncthreads();
+  if (tid < D) {
+    float o = 0.f;
+#pragma unroll
+    for (int g2 = 0; g2 < NG; ++g2) o += sacc[g2 * D + tid];
+    T* Op = (T*)a.O + (int64_t)b * qbs * a.ldo + h * D;
+    Op[tid] = from_f<T>(o / sum);
+    if (tid == 0 && a.LSE) a.LSE[((int64_t)b * a.nh + h) * a.Lq] = mx + __logf(sum);
   }
 }
 
@@ -648,6 +738,12 @@ static int attn_check(const gstvd_attn_t* a, bool bwd) {
 }
 
 template <typename T, int D> static int attn_fwd_launch(const gstvd_attn_t& a, hipStream_t s) {
+  if (a.Lq == 1 && !a.causal && !(a.dropout_p > 0.f && a.rng) && a.Lk <= 8192) {      // the decode step's shape
+    const int ldsd = (D + a.Lk) * 4;
+    hipLaunchKernelGGL((attn_decode_kernel<T, D>), dim3((unsigned)a.nh, (unsigned)a.B), dim3(DEC_NT), ldsd, s, a);
+    GSTVD_LAUNCH_CHECK();
+    return 0;
+  }
   constexpr int lds = 2 * Img<T, D>::BYTES + 64 * 4;
   static int rc = attn_lds_attr(attn_fwd_kernel<T, D>, lds);
   if (rc) return rc;

@@ -53,6 +53,34 @@ DEVFN float wave_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false));  // row_bcast:31 into rows 2, 3
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// Reductions over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48), result in every lane: two gfx950 lane swaps
+// inside the VALU instead of two dependent ds_bpermute round trips (~100 cycles each) through the LDS crossbar.
+//   v_permlane16_swap a, b: rows 1, 3 of a <-> rows 0, 2 of b;   v_permlane32_swap a, b: rows 2, 3 of a <-> rows 0, 1 of b.
+DEVFN void rows_swap16(float& x, float& y) { asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y)); }
+DEVFN void rows_swap32(float& x, float& y) { asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y)); }
+DEVFN float rows_max(float v) {
+  float w = v;
+  rows_swap16(v, w);
+  v = fmaxf(v, w); w = v;
+  rows_swap32(v, w);
+  return fmaxf(v, w);
+}
+DEVFN float rows_sum(float v) {
+  float w = v;
+  rows_swap16(v, w);
+  v += w; w = v;
+  rows_swap32(v, w);
+  return v + w;
+}
+
+// Max over the 64 lanes, result in every lane: DPP inside the 16-lane rows, lane swaps across them (no LDS crossbar trips)
+DEVFN float wave_max_fast(float v) {
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true)));   // quad_perm [1,0,3,2]
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true)));   // quad_perm [2,3,0,1]
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true)));  // row_half_mirror
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true)));  // row_mirror
+  return rows_max(v);
+}
 DEVFN float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -151,6 +151,18 @@ static int gemm_params(const gstvd_gemm_t* g, GemmP& p) {
   return 0;
 }
 
+// Decode step: C = epi(LayerNorm(A; gamma, beta, eps) . B^T) for M <= 16 rows, K <= 1024, bf16 operands (gemv.hip).
+extern "C" int gstvd_gemv_ln(const gstvd_gemm_t* g, const float* gamma, const float* beta, float eps, void* y_out, int64_t ldy,
+                             gstvd_stream_t stream) {
+  GemmP p;
+  const int rc = gemm_params(g, p);
+  if (rc) return rc;
+  if (g->dtype_in != GSTVD_BF16) return GSTVD_E_UNSUPPORTED;
+  if (g->dtype_out != GSTVD_BF16 && g->dtype_out != GSTVD_F32) return GSTVD_E_DTYPE;
+  return gemv16_ln_dispatch(p, g->batch, g->a_kmajor, g->b_kmajor, g->dtype_out == GSTVD_F32, gamma, beta, eps, y_out, ldy,
+                            (hipStream_t)stream);
+}
+
 // Skinny, deep problems (few output tiles, long K: the decoder's 400-row GEMMs, the LM-head input gradient): `splits`
 // workgroups share one 64x64 output tile; see dma_tile in gemm_dma.hip.  `ws` is caller-owned scratch of at least
 // gstvd_gemm_splitk_ws_bytes(M, N, splits) bytes, zero-filled once and never shared by launches that can overlap.

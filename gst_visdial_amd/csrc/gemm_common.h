@@ -246,6 +246,8 @@ int gemm_dma_dispatch(const GemmP& p, int64_t batch, int akm, int bkm, int out_f
 int gemm_dma_splitk_dispatch(const GemmP& p, int akm, int bkm, int out_f32, int S, void* ws, int64_t ws_bytes, hipStream_t s);
 // gemv.hip: M <= 16 (one new token per row of a KV-cached decode step), operands straight from global memory to MFMA fragments
 int gemv16_dispatch(const GemmP& p, int64_t batch, int akm, int bkm, int out_f32, hipStream_t s);
+int gemv16_ln_dispatch(const GemmP& p, int64_t batch, int akm, int bkm, int out_f32, const float* gamma, const float* beta, float eps,
+                       void* y_out, int64_t ldy, hipStream_t s);
 // gemm_dma256.hip: 256x256x32 tile for problems whose grid still fills the chip
 int gemm_dma256_dispatch(const GemmP& p, int64_t batch, int akm, int bkm, int out_f32, hipStream_t s);
 

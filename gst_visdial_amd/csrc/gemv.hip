@@ -56,6 +56,118 @@ __global__ __launch_bounds__(NW * 64) void gemv16_kernel(GemmP p) {
   else st4((bf16*)p.C + m * p.ldc + n, v);
 }
 
+// The same product with a LayerNorm folded into the A operand: C = epi(LN(A; gamma, beta, eps) . B^T), K <= 1024 (a whole row of
+// A sits in the registers of the workgroup's four waves).  In the decode step every LayerNorm is followed by a Linear that
+// reads its output; as a launch of its own the LayerNorm costs as much as that Linear (both are at the ~4-5 us floor of a
+// dependent launch).  Every workgroup normalises the M <= 16 rows itself (24 KB of bf16 from L2), workgroup 0 also writes the
+// normalised rows to y_out -- the residual input of the sub-layer's closing Linear two launches later.
+struct LnIn { const float* gamma; const float* beta; float eps; bf16* y_out; int64_t ldy; };
+
+template <bool F32OUT>
+__global__ __launch_bounds__(256) void gemv16_ln_kernel(GemmP p, LnIn ln) {
+  constexpr int NW = 4, UNR = 8;                              // K <= NW * UNR * 32 = 1024
+  __shared__ f32x4 red[NW][64];
+  __shared__ float rsum[NW][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int64_t n0 = (int64_t)blockIdx.x * 16;
+  const bf16* A = (const bf16*)p.A;
+  const bf16* B = (const bf16*)p.B;
+  const bool av = li < p.M, bv = n0 + li < p.N;
+  const bf16* arow = A + (int64_t)li * p.lda + 8 * g;
+  const bf16* brow = B + (n0 + li) * p.ldb + 8 * g;
+  const int nk = (int)((p.K + 31) / 32);
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const bf16x8 zero = __builtin_bit_cast(bf16x8, (s16x8){0, 0, 0, 0, 0, 0, 0, 0});
+  bf16x8 fa[UNR], fb[UNR];
+  f32x4 gm[UNR][2], bt[UNR][2];                              // gamma / beta of this lane's k positions: loaded with the operands,
+  bool kin[UNR];                                             // one memory round trip for everything
+  const f32x4 zf = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < UNR; ++u) {
+    const int s = wave + u * NW;
+    const int64_t k = (int64_t)s * 32 + 8 * g;
+    kin[u] = s < nk && k < p.K;
+    fa[u] = (kin[u] && av) ? *(const bf16x8*)(arow + (int64_t)s * 32) : zero;
+    fb[u] = (kin[u] && bv) ? *(const bf16x8*)(brow + (int64_t)s * 32) : zero;
+    gm[u][0] = kin[u] ? *(const f32x4*)(ln.gamma + k) : zf;
+    gm[u][1] = kin[u] ? *(const f32x4*)(ln.gamma + k + 4) : zf;
+    bt[u][0] = kin[u] ? *(const f32x4*)(ln.beta + k) : zf;
+    bt[u][1] = kin[u] ? *(const f32x4*)(ln.beta + k + 4) : zf;
+  }
+  // row statistics, two passes over the registers like layernorm.hip (mean, then the centred second moment)
+  auto row_total = [&](float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);                               // over the four k-groups of the wave
+    __syncthreads();
+    if (g == 0) rsum[wave][li] = v;
+    __syncthreads();
+    return rsum[0][li] + rsum[1][li] + rsum[2][li] + rsum[3][li];
+  };
+  float s1 = 0.f;
+#pragma unroll
+  for (int u = 0; u < UNR; ++u)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s1 += (float)fa[u][j];       // (elements outside K / M are zero)
+  const float mean = row_total(s1) / (float)p.K;
+  float s2 = 0.f;
+#pragma unroll
+  for (int u = 0; u < UNR; ++u)
+    if (kin[u])
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = (float)fa[u][j] - mean; s2 += d * d; }
+  const float rstd = 1.0f / sqrtf(row_total(s2) / (float)p.K + ln.eps);      // (same form as layernorm.hip)
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < UNR; ++u) {
+    if (kin[u]) {                                             // (uniform per 16-lane group; MFMA below is outside the branch)
+      const int64_t k = (int64_t)(wave + u * NW) * 32 + 8 * g;
+      const f32x4 g0 = gm[u][0], g1 = gm[u][1], b0 = bt[u][0], b1 = bt[u][1];
+      bf16x8 y;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        y[j] = (bf16)(((float)fa[u][j] - mean) * rstd * g0[j] + b0[j]);
+        y[j + 4] = (bf16)(((float)fa[u][j + 4] - mean) * rstd * g1[j] + b1[j]);
+      }
+      fa[u] = av ? y : zero;
+      if (blockIdx.x == 0 && ln.y_out && av) *(bf16x8*)(ln.y_out + (int64_t)li * ln.ldy + k) = y;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < UNR; ++u) acc = mfma_bf16_k32(fb[u], fa[u], acc);
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int w = 1; w < NW; ++w) acc += red[w][lane];
+  const int64_t m = li, n = n0 + 4 * g;
+  if (m >= p.M || n >= p.N) return;
+  f32x4 v = acc * p.alpha;
+  if (p.epi & GSTVD_EPI_BIAS) v += *(const f32x4*)(p.bias + n);
+  if (p.epi & GSTVD_EPI_ADD) v += ld4((const bf16*)p.addend + m * p.ldadd + n);
+  if (p.epi & GSTVD_EPI_GELU) {
+    f32x4 d;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { float g_, d_; gelu_both<true>(v[e], g_, d_); v[e] = g_; d[e] = d_; }
+    if (p.aux) st4((bf16*)p.aux + m * p.ldaux + n, d);
+  }
+  if (F32OUT) st4((float*)p.C + m * p.ldc + n, v);
+  else st4((bf16*)p.C + m * p.ldc + n, v);
+}
+
+int gemv16_ln_dispatch(const GemmP& p, int64_t batch, int akm, int bkm, int out_f32, const float* gamma, const float* beta, float eps,
+                       void* y_out, int64_t ldy, hipStream_t s) {
+  if (p.M > 16 || p.K > 1024 || batch != 1 || akm || bkm) return GSTVD_E_UNSUPPORTED;
+  if (p.epi & (GSTVD_EPI_DGELU | GSTVD_EPI_DROPOUT)) return GSTVD_E_UNSUPPORTED;
+  if (!gamma || !beta) return GSTVD_E_NULL;
+  if (y_out && ((ldy % 8) || ((uintptr_t)y_out & 15))) return GSTVD_E_ALIGN;
+  LnIn ln{gamma, beta, eps, (bf16*)y_out, ldy};
+  const dim3 grid((unsigned)((p.N + 15) / 16));
+  if (out_f32) GSTVD_LAUNCH((gemv16_ln_kernel<true>), grid, dim3(256), 0, s, p, ln);
+  else GSTVD_LAUNCH((gemv16_ln_kernel<false>), grid, dim3(256), 0, s, p, ln);
+  GSTVD_LAUNCH_CHECK();
+  return 0;
+}
+
 // returns GSTVD_E_UNSUPPORTED when the problem is not of this shape (the caller falls through to the tiled kernels)
 int gemv16_dispatch(const GemmP& p, int64_t batch, int akm, int bkm, int out_f32, hipStream_t s) {
   if (p.M > 16 || batch != 1 || akm || bkm) return GSTVD_E_UNSUPPORTED;

@@ -10,51 +10,68 @@
 
 namespace {
 
-constexpr int NT = 256;
+constexpr int NT = 1024, NWV = NT / 64;
 
-// block reduction of (max value, how many elements carry it)
-DEVFN void reduce_maxcount(float& m, int& c, float* smf, int* smi, int tid) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float om = __shfl_xor(m, o, 64);
-    const int oc = __shfl_xor(c, o, 64);
-    if (om > m) { m = om; c = oc; }
-    else if (om == m) c += oc;
-  }
+// block reduction of (max value, how many elements carry it); counts travel as floats (exact below 2^24)
+DEVFN void reduce_maxcount(float& m, int& c, float* smf, float* smc, int tid) {
+  const float wm = wave_max_fast(m);
+  const float wc = wave_sum(m == wm ? (float)c : 0.f);
   const int w = tid >> 6;
   __syncthreads();
-  if ((tid & 63) == 0) { smf[w] = m; smi[w] = c; }
+  if ((tid & 63) == 0) { smf[w] = wm; smc[w] = wc; }
   __syncthreads();
-  m = smf[0]; c = smi[0];
+  float bm = -INFINITY, bc = 0.f;
 #pragma unroll
-  for (int i = 1; i < NT / 64; ++i) {
-    if (smf[i] > m) { m = smf[i]; c = smi[i]; }
-    else if (smf[i] == m) c += smi[i];
+  for (int i = 0; i < NWV; i += 4) {
+    const f32x4 vm = *(const f32x4*)(smf + i), vc = *(const f32x4*)(smc + i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (vm[j] > bm) { bm = vm[j]; bc = vc[j]; }
+      else if (vm[j] == bm) bc += vc[j];
+    }
   }
+  m = bm; c = (int)bc;
 }
 
 template <typename T>
 __global__ __launch_bounds__(NT) void sample_topk_kernel(gstvd_sample_t a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* z = (float*)smem;                                   // [V]
-  __shared__ float smf[NT / 64];
-  __shared__ int smi[NT / 64];
-  __shared__ float spart[NT];
-  __shared__ int scnt[NT / 64];
-  const int tid = threadIdx.x, b = blockIdx.x, V = a.V;
+  __shared__ __attribute__((aligned(16))) float smf[NWV];
+  __shared__ __attribute__((aligned(16))) float smc[NWV];
+  __shared__ int smi[NWV];
+  __shared__ float swave[NWV];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x, V = a.V;
   const T* row = (const T*)a.logits + (int64_t)b * a.ld;
   const uint8_t* ban = a.banned ? a.banned + (int64_t)b * a.banned_ld : nullptr;
 
+  // the row: element i = tid + j * NT lives in register zr[j] of thread tid (for the top-k passes) and in z[i] (LDS, for the
+  // ordered CDF pass below); all of a thread's loads are issued before the first use
+  constexpr int SEG = 31;                                     // V <= 31 * 1024 (checked by the host entry)
+  float zr[SEG];
+  uint8_t bn[SEG];
+#pragma unroll
+  for (int j = 0; j < SEG; ++j) {
+    const int i = tid + j * NT;
+    zr[j] = i < V ? to_f(row[i]) : 0.f;
+    bn[j] = (ban && i < V) ? ban[i] : (uint8_t)0;
+  }
   float m = -INFINITY;
   int c = 0;
-  for (int i = tid; i < V; i += NT) {
-    float v = to_f(row[i]) / a.temperature;
-    if (ban && ban[i]) v = -INFINITY;
-    z[i] = v;
-    if (v > m) { m = v; c = 1; }
-    else if (v == m) ++c;
+#pragma unroll
+  for (int j = 0; j < SEG; ++j) {
+    const int i = tid + j * NT;
+    float v = -INFINITY;
+    if (i < V) {
+      v = zr[j] / a.temperature;                             // (a true division, like the reference's logits / temperature)
+      if (bn[j]) v = -INFINITY;
+      z[i] = v;
+      if (v > m) { m = v; c = 1; }
+      else if (v == m) ++c;
+    }
+    zr[j] = v;                                               // (-inf past the end: never selected, never counted below)
   }
-  reduce_maxcount(m, c, smf, smi, tid);                      // (also orders the z[] writes before the reads below)
+  reduce_maxcount(m, c, smf, smc, tid);                      // (also orders the z[] writes before the reads below)
   const float zmax = m;
   float kth = -INFINITY;
   if (a.top_k > 0) {
@@ -64,52 +81,72 @@ __global__ __launch_bounds__(NT) void sample_topk_kernel(gstvd_sample_t a) {
     while (have < k) {                                       // uniform: every thread holds the same (thr, have)
       float m2 = -INFINITY;
       int c2 = 0;
-      for (int i = tid; i < V; i += NT) {
-        const float v = z[i];
-        if (v < thr) {
-          if (v > m2) { m2 = v; c2 = 1; }
-          else if (v == m2) ++c2;
-        }
+#pragma unroll
+      for (int j = 0; j < SEG; ++j) {                      // branch-free: selects only (an all -inf remainder may count garbage
+        const float v = zr[j] < thr ? zr[j] : -INFINITY;     // into c2 -- it is discarded below when m2 comes out as -inf)
+        const bool gt = v > m2, eq = v == m2;
+        c2 = gt ? 1 : (eq ? c2 + 1 : c2);
+        m2 = gt ? v : m2;
       }
-      reduce_maxcount(m2, c2, smf, smi, tid);
-      if (c2 == 0) { thr = -INFINITY; break; }               // nothing below thr (only possible when -inf entries are all that is left)
+      // (entries that are -inf -- banned or past the end -- count as "nothing left": c2 of an all -inf remainder is dropped)
+      reduce_maxcount(m2, c2, smf, smc, tid);
+      if (c2 == 0 || m2 == -INFINITY) { thr = -INFINITY; break; }
       thr = m2;
       have += c2;
     }
     kth = thr;
   }
   // inverse CDF over e_i = [z_i >= kth] * exp(z_i - zmax): thread t owns the contiguous segment [t * seg, (t + 1) * seg)
-  const int seg = (V + NT - 1) / NT;
+  // (seg odd: the threads' LDS reads fall into different banks); the segment's weights stay in registers for the second pass
+  constexpr int SEGMAX = SEG;
+  const int seg = ((V + NT - 1) / NT) | 1;
   const int i0 = tid * seg, i1 = (i0 + seg < V) ? i0 + seg : V;
+  float e[SEGMAX];
   float s = 0.f;
-  for (int i = i0; i < i1; ++i) {
-    const float v = z[i];
-    s += (v >= kth && v > -INFINITY) ? expf(v - zmax) : 0.f;
+#pragma unroll
+  for (int j = 0; j < SEGMAX; ++j) {
+    const int i = i0 + j;
+    float w = 0.f;
+    if (j < seg && i < i1) {
+      const float v = z[i];
+      w = (v >= kth && v > -INFINITY) ? __expf(v - zmax) : 0.f;
+    }
+    e[j] = w;
+    s += w;
   }
-  spart[tid] = s;
+  // exclusive prefix of s over the 1024 threads: wave scan, then the 16 wave totals
+  float inc = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float up = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += up;
+  }
+  if (lane == 63) swave[wave] = inc;
   __syncthreads();
-  float pre = 0.f, total = 0.f;
-  for (int t = 0; t < NT; ++t) {                             // 256 LDS broadcasts: negligible next to the row passes
-    const float v = spart[t];
-    if (t < tid) pre += v;
-    total += v;
+  float pre = inc - s, total = 0.f;
+#pragma unroll
+  for (int w = 0; w < NWV; ++w) {
+    const float t = swave[w];
+    if (w < wave) pre += t;
+    total += t;
   }
   const float x = a.u[b] * total;
   int cnt = 0;
   float run = pre;
-  for (int i = i0; i < i1; ++i) {
-    const float v = z[i];
-    run += (v >= kth && v > -INFINITY) ? expf(v - zmax) : 0.f;
-    cnt += run < x ? 1 : 0;
+#pragma unroll
+  for (int j = 0; j < SEGMAX; ++j) {
+    run += e[j];
+    cnt += (j < seg && i0 + j < i1 && run < x) ? 1 : 0;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-  if ((tid & 63) == 0) scnt[tid >> 6] = cnt;
+  __syncthreads();
+  if (lane == 0) smi[wave] = cnt;
   __syncthreads();
   if (tid == 0) {
     int idx = 0;
 #pragma unroll
-    for (int i = 0; i < NT / 64; ++i) idx += scnt[i];
+    for (int i = 0; i < NWV; ++i) idx += smi[i];
     if (idx > V - 1) idx = V - 1;
     a.out[(int64_t)b * a.out_stride] = idx;
   }
@@ -135,7 +172,7 @@ extern "C" int gstvd_sample_topk(const gstvd_sample_t* a, gstvd_stream_t stream)
   if (!a || !a->logits || !a->u || !a->out) return GSTVD_E_NULL;
   if (a->dtype != GSTVD_F32 && a->dtype != GSTVD_BF16) return GSTVD_E_DTYPE;
   if (a->B <= 0 || a->V <= 0 || a->ld < a->V || a->top_k < 0 || !(a->temperature > 0.f)) return GSTVD_E_SHAPE;
-  if ((int64_t)a->V * 4 > 150 * 1024) return GSTVD_E_UNSUPPORTED;          // the row must fit the CU's LDS
+  if (a->V > 31 * 1024) return GSTVD_E_UNSUPPORTED;                         // the row must fit the CU's LDS (and 31 weights per thread)
   hipStream_t s = (hipStream_t)stream;
   return a->dtype == GSTVD_BF16 ? launch<bf16>(*a, s) : launch<float>(*a, s);
 }

@@ -931,13 +931,38 @@ class Engine(object):
             prefix = "emb" if self.flat.dec_emb is self.flat.enc_emb else "demb"
             self.arena.rewind(st["mark"])
             y = self.embed(prefix, tok.contiguous(), None, Bn, 1, dc, pos_offset=t)
+            # bf16: the three LayerNorms of a layer are folded into the Linears that read them (gstvd_gemv_ln) and the residual
+            # adds into the epilogues of the Linears in front of them -- 8 launches per layer instead of 11.  `pre` = the
+            # rows whose LayerNorm (parameters `lnp`) the next Linear still has to apply.
+            fuse = self.adt is torch.bfloat16 and Bn <= 16 and H <= 1024
+            I_ = dc.intermediate_size
+            pre, lnp = None, None
             for i in range(L):
                 p = "d%d" % i
                 rows_t = QKVc[i].t.view(Bn, Umax, 3 * H)[:, t]                     # [Bn, 3H] view, row stride Umax * 3H
-                ops.gemm(y.t, self.W[p + ".qkv.w"], rows_t, Bn, 3 * H, H, bias=self.Pv[p + ".qkv.b"])
+                if pre is None:
+                    ops.gemm(y.t, self.W[p + ".qkv.w"], rows_t, Bn, 3 * H, H, bias=self.Pv[p + ".qkv.b"])
+                else:
+                    y = self.act(Bn, H)
+                    ops.gemv_ln(pre.t, self.W[p + ".qkv.w"], rows_t, Bn, 3 * H, H, self.Pv[lnp + ".w"], self.Pv[lnp + ".b"], eps,
+                                y_out=y.t, bias=self.Pv[p + ".qkv.b"])
                 qkv = Act(rows_t, Bn, 3 * H)
                 ctx = self.attn((qkv, 0), (QKVc[i], H), (QKVc[i], 2 * H), Bn, nh, 1, t + 1, d, None, False, -10000.0, 0.0,
                                 kv_bstride=Umax)
+                if fuse:
+                    pre1, y1, q = self.act(Bn, H), self.act(Bn, H), self.act(Bn, H)
+                    ops.gemm(ctx.t, self.W[p + ".ao.w"], pre1.t, Bn, H, H, bias=self.Pv[p + ".ao.b"], addend=y.t)
+                    ops.gemv_ln(pre1.t, self.W[p + ".cq.w"], q.t, Bn, H, H, self.Pv[p + ".ln1.w"], self.Pv[p + ".ln1.b"], eps,
+                                y_out=y1.t, bias=self.Pv[p + ".cq.b"])
+                    ctx = self.attn((q, 0), (kv, 2 * i * H), (kv, (2 * i + 1) * H), Bn, nh, 1, S, d, I["emask"], False, -1e9, 0.0)
+                    pre2, y2, a, aux = self.act(Bn, H), self.act(Bn, H), self.act(Bn, I_), self.buf(Bn, I_)
+                    ops.gemm(ctx.t, self.W[p + ".co.w"], pre2.t, Bn, H, H, bias=self.Pv[p + ".co.b"], addend=y1.t)
+                    ops.gemv_ln(pre2.t, self.W[p + ".fi.w"], a.t, Bn, I_, H, self.Pv[p + ".ln2.w"], self.Pv[p + ".ln2.b"], eps,
+                                y_out=y2.t, bias=self.Pv[p + ".fi.b"], aux=aux, epi=EPI_GELU)
+                    pre = self.act(Bn, H)
+                    ops.gemm(a.t, self.W[p + ".fo.w"], pre.t, Bn, H, I_, bias=self.Pv[p + ".fo.b"], addend=y2.t)
+                    lnp = p + ".ln3"
+                    continue
                 ao = self.lin(ctx, p + ".ao.w", p + ".ao.b", H, H)
                 y1 = self.ln(ao, y, p + ".ln1.w", p + ".ln1.b", H, 0.0, None, eps)
                 q = self.lin(y1, p + ".cq.w", p + ".cq.b", H, H)
@@ -947,7 +972,11 @@ class Engine(object):
                 a = self.lin(y2, p + ".fi.w", p + ".fi.b", dc.intermediate_size, H, gelu=True)
                 fo = self.lin(a, p + ".fo.w", p + ".fo.b", H, dc.intermediate_size)
                 y = self.ln(fo, y2, p + ".ln3.w", p + ".ln3.b", H, 0.0, None, eps)
-            return self.lin(y, "lm.w", "lm.b", Vp, H).t[:, :V].float()
+            if pre is not None:
+                # (the LM head keeps LayerNorm + Linear as two launches: 1908 workgroups of the LN-in kernel, each holding
+                # gamma / beta in registers, stream the 47 MB of vocabulary weights at a quarter of the plain kernel's rate)
+                y = self.ln(pre, None, lnp + ".w", lnp + ".b", H, 0.0, None, eps)
+            return self.lin(y, "lm.w", "lm.b", Vp, H).t[:, :V]         # [Bn, V] view of the arena (row stride Vp), activation dtype
 
         return encode, one_token, st
 
@@ -959,19 +988,21 @@ class Engine(object):
 
     @staticmethod
     def _sampling_step(logits, cur, pos, hist, P, u_row):
-        """One step of models/visual_dialog_model.py:96-108 on static buffers: cur[:, pos] <- the token drawn from `logits`
+        """One step of models/visual_dialog_model.py:96-108 on static buffers: cur[pos] <- the token drawn from `logits`
         (temperature, n-gram ban against `hist`, top-k / top-p, softmax, inverse-CDF draw from the uniforms `u_row`).
-        Free of host synchronisation and of generator state, so the token graph captures it together with the decoder stack."""
+        `cur` is the TIME-MAJOR id buffer [L0 + max_seq_len, B]: position t of all rows is one contiguous row, which the next
+        token step's embedding reads as it is.  Free of host synchronisation and of generator state, so the token graph
+        captures it together with the decoder stack."""
         from . import decoding
         if Engine._fused_sampling(P):
-            banned = decoding.ngram_banned_mask(hist, cur[:, :pos], P["ngram"], logits.shape[-1], logits.device)
-            ops.sample_topk(logits, P["temperature"], P["top_k"], u_row, cur[:, pos], banned)
+            banned = decoding.ngram_banned_mask(hist, cur[:pos].t(), P["ngram"], logits.shape[-1], logits.device)
+            ops.sample_topk(logits, P["temperature"], P["top_k"], u_row, cur[pos], banned)
             return
-        last = logits / P["temperature"]
-        last = decoding.batch_ngram_blocking(last, hist, cur[:, :pos], ngram_size=P["ngram"])
+        last = logits.float() / P["temperature"]
+        last = decoding.batch_ngram_blocking(last, hist, cur[:pos].t(), ngram_size=P["ngram"])
         last = decoding.batch_top_k_top_p_sampling(last, top_k=P["top_k"], top_p=P["top_p"])
         prob = torch.softmax(last, dim=-1)
-        cur[:, pos] = decoding.draw_from_uniform(prob, u_row).view(-1)
+        cur[pos] = decoding.draw_from_uniform(prob, u_row).view(-1)
 
     def _decode_session(self, ins, L0, max_seq_len, P):
         """hipGraph form of a decode call (generate.py's loop calls sample() with the same shapes and settings batch after
@@ -984,7 +1015,7 @@ class Engine(object):
         ids, segs, dec_ids = static[3], static[4], static[6]
         Bn, dev = ids.shape[0], ids.device
         steps = L0 + max_seq_len - 1
-        cur = torch.zeros(Bn, L0 + max_seq_len, dtype=torch.long, device=dev)
+        cur = torch.zeros(L0 + max_seq_len, Bn, dtype=torch.long, device=dev)      # time-major (see _sampling_step)
         u_buf = torch.zeros(max_seq_len, Bn, dtype=torch.float32, device=dev)
         encode, one_token, st = self._decode_plan(static, L0, max_seq_len)
         from .graph import capture, gc_quiet
@@ -995,9 +1026,9 @@ class Engine(object):
                 hist = ids * (segs == 0).long()
             g_dec = torch.cuda.CUDAGraph()
             with capture(g_dec, pool=g_enc.pool(), quiesce=False):
-                cur[:, :L0] = dec_ids
+                cur[:L0] = dec_ids.t()
                 for t in range(steps):
-                    logits = one_token(cur[:, t], t)
+                    logits = one_token(cur[t], t)
                     if t >= L0 - 1:
                         self._sampling_step(logits, cur, t + 1, hist, P, u_buf[t - (L0 - 1)])
 
@@ -1055,16 +1086,16 @@ class Engine(object):
             run_encode, one_token, dst = self._decode_plan(ins, L0, max_seq_len)
             run_encode()
             hist = ids * (segs == 0).long()
-            cur = torch.zeros(Bn, L0 + max_seq_len, dtype=torch.long, device=ids.device)
-            cur[:, :L0] = dec_ids
+            cur = torch.zeros(L0 + max_seq_len, Bn, dtype=torch.long, device=ids.device)
+            cur[:L0] = dec_ids.t()
             for t in range(L0 + max_seq_len - 1):
-                logits = one_token(cur[:, t], t)
+                logits = one_token(cur[t], t)
                 if t >= L0 - 1:                            # (earlier positions only consume the given prefix)
                     self._sampling_step(logits, cur, t + 1, hist, P, u[t - (L0 - 1)])
-        self.last = dict(decode_logits=logits)            # last position's raw logits (tests / debugging)
+        self.last = dict(decode_logits=logits.float())    # last position's raw logits (tests / debugging)
         # the encoder side of this call (cross-attention K/V of all layers, masks) stays valid in the arena until the next
         # engine call: `rescore_sampled` scores the sampled answer against it without a second encoder pass
-        out = decoding.pad_after_eos(cur[:, L0:], dc.eos_token_id, dc.pad_token_id)
+        out = decoding.pad_after_eos(cur[L0:].t().contiguous(), dc.eos_token_id, dc.pad_token_id)
         if use_graph and sess is None:
             # first call with these shapes ran eagerly (it also initialised every lazily built table / attribute / arena
             # chunk); capture now so the next batch replays

@@ -163,6 +163,30 @@ def gemm(A, B, C_out, M, N, K, *, a_km=False, b_km=False, bias=None, addend=None
     return C_out
 
 
+def gemv_ln(A, B, C_out, M, N, K, gamma, beta, eps, y_out=None, bias=None, addend=None, aux=None, epi=0):
+    """C[M <= 16, N] = epi(LayerNorm(A[M, K]; gamma, beta, eps) . B[N, K]^T), bf16 operands (gstvd_gemv_ln): the decode step's
+    LayerNorm -> Linear pairs as one launch; y_out [M, K] bf16 (optional) receives the normalised rows."""
+    lib = L.load()
+    d = L.GemmDesc()
+    d.A, d.B, d.C = _p(A), _p(B), _p(C_out)
+    d.bias, d.addend, d.aux = _p(bias), _p(addend), _p(aux)
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc = A.stride(-2), B.stride(-2), C_out.stride(-2)
+    d.ldadd = addend.stride(-2) if addend is not None else 0
+    d.ldaux = aux.stride(-2) if aux is not None else 0
+    d.batch, d.dtype_in, d.dtype_out, d.alpha = 1, dt(A), dt(C_out), 1.0
+    if bias is not None:
+        epi |= EPI_BIAS
+    if addend is not None:
+        epi |= EPI_ADD
+    d.epilogue = epi
+    e0 = _prof_begin()
+    L.check("gstvd_gemv_ln", lib.gstvd_gemv_ln(C.byref(d), _p(gamma), _p(beta), float(eps), _p(y_out),
+                                              y_out.stride(-2) if y_out is not None else 0, _stream()))
+    _prof_end(e0, "gemv_ln", 2.0 * M * N * K, float((M * K + N * K) * 2 + M * N * C_out.element_size()), (M, N, K, 1))
+    return C_out
+
+
 SPLITK = int(os.environ.get("GSTVD_GEMM_SPLITK", "1"))
 _SPLITK_WS = {}
 

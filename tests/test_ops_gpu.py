@@ -489,6 +489,34 @@ def test_gemm_grouped_column_sums():
     assert torch.allclose(gb, before + dy.float().sum(0), rtol=1e-5, atol=1e-3)
 
 
+@pytest.mark.parametrize("M,N,K", [(16, 768, 768), (16, 2304, 768), (5, 136, 200), (16, 3072, 1024), (3, 30528, 768)])
+def test_decode_layernorm_folded_into_the_linear(M, N, K):
+    """gstvd_gemv_ln: C = epi(LN(A) . B^T) for the decode step's rows -- against LayerNorm (fp32 arithmetic on the bf16 rows,
+    bf16 result) followed by the skinny GEMM; the normalised rows come back through y_out; bias / residual add / GELU."""
+    o = ops()
+    x = rnd(M, K, dtype=torch.bfloat16, seed=60, s=1.7) + 0.3
+    w, b = rnd(N, K, dtype=torch.bfloat16, seed=61, s=0.1), rnd(N, seed=62)
+    gam, bet = rnd(K, seed=63) * 0.2 + 1.0, rnd(K, seed=64) * 0.1
+    yn = torch.nn.functional.layer_norm(x.float(), (K,), gam, bet, 1e-12).to(torch.bfloat16)
+    ref = yn.float() @ w.float().t() + b
+    big = torch.zeros(M, 3, N, device=DEV, dtype=torch.bfloat16)
+    c, yo = big[:, 1], torch.zeros(M, K, device=DEV, dtype=torch.bfloat16)
+    o.gemv_ln(x, w, c, M, N, K, gam, bet, 1e-12, y_out=yo, bias=b)
+    # the normalised rows: bf16 roundings of the same fp32 values (an ulp where the two roundings straddle a tie)
+    assert (yo.float() - yn.float()).abs().max().item() <= 2.0 ** -7 * max(1.0, yn.float().abs().max().item())
+    check("gemv_ln", c.contiguous(), ref, torch.bfloat16, 2.0)
+    assert float(big[:, 0].abs().max()) == 0.0 and float(big[:, 2].abs().max()) == 0.0
+    r = rnd(M, N, dtype=torch.bfloat16, seed=65)
+    c2 = torch.empty(M, N, device=DEV, dtype=torch.float32)
+    o.gemv_ln(x, w, c2, M, N, K, gam, bet, 1e-12, bias=b, addend=r)
+    check("gemv_ln_add_f32out", c2, ref + r.float(), torch.bfloat16, 2.0)
+    a, u = torch.empty(M, N, device=DEV, dtype=torch.bfloat16), torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    o.gemv_ln(x, w, a, M, N, K, gam, bet, 1e-12, bias=b, aux=u, epi=o.EPI_GELU)
+    check("gemv_ln_gelu", a, torch.nn.functional.gelu(ref), torch.bfloat16, 2.0)
+    with pytest.raises(Exception):                                   # rows that do not fit the kernel are refused, not mangled
+        o.gemv_ln(rnd(17, K, dtype=torch.bfloat16, seed=1), w, torch.empty(17, N, device=DEV, dtype=torch.bfloat16), 17, N, K, gam, bet, 1e-12)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("V", [97, 30522])
 def test_sample_topk_matches_the_torch_filters_and_inverse_cdf(dtype, V):
