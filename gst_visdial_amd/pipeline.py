@@ -12,8 +12,8 @@ which -- on the engine's auxiliary stream, i.e. concurrently with the remaining 
 
 It is the ONE gradient-synchronisation path of this package (round 1 also carried a second, hook-based bucketed all-reduce,
 `dp.GradSync`, that duplicated the slicing logic and was not on the bench path; it is gone).  Sizing: xGMI is point to point
-(7 links x ~153 GB/s per GPU), a ring all-reduce is per-link bound, so slices are few and large (graded: 128, 48, 48, 32, 32,
-24 Mi elements at N>1 -- the first, largest one has the whole encoder backward to hide behind, the last ones keep the exposed
+(7 links x ~153 GB/s per GPU), a ring all-reduce is per-link bound, so slices are few and large (graded: 128, 96, 96, 32,
+16 Mi elements at N>1 -- the first, largest one has the whole encoder backward to hide behind, the last ones keep the exposed
 tail short) instead of hundreds of small buckets.
 
 This is the MI355X-native replacement of nn.DataParallel's per-step parameter broadcast + gradient reduce-add

@@ -11,7 +11,7 @@ names = {"bench_n1.json": "bench_n1.json", "breakdown_events.json": "breakdown_e
          "h2d_probe.txt": "h2d_probe.txt", "eval_decode.json": "eval_decode.json", "gpu_tests_full.log": "gpu_tests_full.log",
          "bench_force_dist_rows16.json": "bench_force_dist_rows16.json", "bench_force_dist_rows10.json": "bench_force_dist_rows10.json",
          "bench_n1_rows10.json": "bench_n1_rows10.json", "decode_attention_kernels.txt": "decode_attention_kernels.txt",
-         "slice_sweep.txt": "slice_sweep.txt"}
+         "slice_sweep.txt": "slice_sweep.txt", "dist_slice_sweep.txt": "dist_slice_sweep.txt"}
 for a, b in names.items():
     p = os.path.join(src, a)
     if os.path.exists(p):

@@ -35,6 +35,7 @@ rocprofv3 --kernel-trace --output-format csv -d $out/dec_trace -- python3 tools/
 ( python3 tools/decode_timeline.py $out/dec_trace; python3 tools/sample_probe.py 2>/dev/null | grep top_k; bash tools/attn_shapes.sh 2>/dev/null | grep "^attn" ) > $out/decode_attention_kernels.txt 2>&1; rm -rf $out/dec_trace
 # 10c. N = 1 sweep of the backward pipeline's slice sizes, with / without a separate AdamW stream
 bash tools/slice_sweep.sh > /dev/null 2>&1; cp gpurun_out/r2/slice_sweep.txt $out/slice_sweep.txt
+bash tools/dist_slice_sweep.sh > /dev/null 2>&1; cp gpurun_out/r2/dist_slice_sweep.txt $out/dist_slice_sweep.txt
 cut -c1-400 $out/bench_n1.json; tail -3 $out/gpu_tests_full.log; head -6 $out/kernel_stats_bench.csv | cut -c1-150
 # 11. the N>1 code path on one GPU (1-rank RCCL group: collectives, graded slices, bf16 payload, graph capture), both row counts
 for rows in 16 10; do GSTVD_FORCE_DIST=1 python3 bench.py --steps 10 --warmup 2 --rows-per-gpu $rows --grad-compress bf16 --no-cpu-baseline --no-breakdown --no-fp32 --no-h2d 2>/dev/null | tail -1 > $out/bench_force_dist_rows$rows.json; done
