@@ -1070,7 +1070,11 @@ class Engine(object):
             # torch.multinomial (whose stream is device specific anyway), and the same ids from eager issue and graph replay
             u = torch.rand(max_seq_len, Bn, device=ids.device, dtype=torch.float32).clamp_min_(1e-12)
         else:
-            u = uniforms.to(ids.device, torch.float32).contiguous()
+            u = uniforms.to(ids.device, torch.float32)
+            if u.dim() != 2 or u.shape[0] < max_seq_len or u.shape[1] != Bn:
+                raise GstvdError("uniforms must be [max_seq_len = %d, batch = %d] (one draw per step and row), got %s"
+                                 % (max_seq_len, Bn, tuple(u.shape)))
+            u = u[:max_seq_len].contiguous()
         use_graph = bool(self.model.params.get("amd_decode_graph", True)) and self._fused_sampling(P)
         # parameters edited since the last call (load_state_dict, an optimizer step): the captured graphs read the flat
         # buffers / bf16 shadow, so bring those up to date OUTSIDE the graphs; a re-materialised buffer drops the sessions
