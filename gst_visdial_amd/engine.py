@@ -981,10 +981,11 @@ class Engine(object):
         return encode, one_token, st
 
     @staticmethod
-    def _fused_sampling(P):
-        """The fused sampling kernel covers the reference's settings (generate.py:138-141,177-180: top_k 7, top_p 0); top-p or
-        a very wide top-k take the torch-op form of the filters, issued eagerly step by step (no captured token graph)."""
-        return P["top_p"] <= 0.0 and P["top_k"] <= ops.SAMPLE_MAX_TOP_K
+    def _fused_sampling(P, vocab):
+        """The fused sampling kernel covers the reference's settings (generate.py:138-141,177-180: top_k 7, top_p 0; BERT's
+        30522-token vocabulary); top-p, a very wide top-k or a vocabulary beyond one CU's LDS take the torch-op form of the
+        filters, issued eagerly step by step (no captured token graph)."""
+        return P["top_p"] <= 0.0 and P["top_k"] <= ops.SAMPLE_MAX_TOP_K and vocab <= ops.SAMPLE_MAX_VOCAB
 
     @staticmethod
     def _sampling_step(logits, cur, pos, hist, P, u_row):
@@ -994,7 +995,7 @@ class Engine(object):
         token step's embedding reads as it is.  Free of host synchronisation and of generator state, so the token graph
         captures it together with the decoder stack."""
         from . import decoding
-        if Engine._fused_sampling(P):
+        if Engine._fused_sampling(P, logits.shape[-1]):
             banned = decoding.ngram_banned_mask(hist, cur[:pos].t(), P["ngram"], logits.shape[-1], logits.device)
             ops.sample_topk(logits, P["temperature"], P["top_k"], u_row, cur[pos], banned)
             return
@@ -1075,7 +1076,7 @@ class Engine(object):
                 raise GstvdError("uniforms must be [max_seq_len = %d, batch = %d] (one draw per step and row), got %s"
                                  % (max_seq_len, Bn, tuple(u.shape)))
             u = u[:max_seq_len].contiguous()
-        use_graph = bool(self.model.params.get("amd_decode_graph", True)) and self._fused_sampling(P)
+        use_graph = bool(self.model.params.get("amd_decode_graph", True)) and self._fused_sampling(P, dc.vocab_size)
         # parameters edited since the last call (load_state_dict, an optimizer step): the captured graphs read the flat
         # buffers / bf16 shadow, so bring those up to date OUTSIDE the graphs; a re-materialised buffer drops the sessions
         self.prepare(ids.device)

@@ -516,6 +516,7 @@ def ce_bwd(logits, labels, lse, stats, gscale, mean, M, V, dlogits, ignore_index
 
 
 SAMPLE_MAX_TOP_K = 64      # beyond this (or with top-p) the filter runs as torch ops (decoding.batch_top_k_top_p_sampling)
+SAMPLE_MAX_VOCAB = 31 * 1024   # a row of scaled logits lives in one CU's LDS (and 31 registers per thread)
 
 
 def sample_topk(logits, temperature, top_k, u, out, banned=None):
