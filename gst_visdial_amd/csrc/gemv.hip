@@ -67,7 +67,7 @@ template <bool F32OUT>
 __global__ __launch_bounds__(256) void gemv16_ln_kernel(GemmP p, LnIn ln) {
   constexpr int NW = 4, UNR = 8;                              // K <= NW * UNR * 32 = 1024
   __shared__ f32x4 red[NW][64];
-  __shared__ float rsum[NW][16];
+  __shared__ float rsum[NW][16], rsq[NW][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   const int64_t n0 = (int64_t)blockIdx.x * 16;
   const bf16* A = (const bf16*)p.A;
@@ -94,28 +94,20 @@ __global__ __launch_bounds__(256) void gemv16_ln_kernel(GemmP p, LnIn ln) {
     bt[u][0] = kin[u] ? *(const f32x4*)(ln.beta + k) : zf;
     bt[u][1] = kin[u] ? *(const f32x4*)(ln.beta + k + 4) : zf;
   }
-  // row statistics, two passes over the registers like layernorm.hip (mean, then the centred second moment)
-  auto row_total = [&](float v) {
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);                               // over the four k-groups of the wave
-    __syncthreads();
-    if (g == 0) rsum[wave][li] = v;
-    __syncthreads();
-    return rsum[0][li] + rsum[1][li] + rsum[2][li] + rsum[3][li];
-  };
-  float s1 = 0.f;
+  // row statistics in ONE reduction round (sum and sum of squares together; fp32, var = E[x^2] - mean^2 clamped at 0: the
+  // rows are residual-stream activations, |mean| is far below the spread, nothing cancels) -- two barriers instead of four
+  float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int u = 0; u < UNR; ++u)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s1 += (float)fa[u][j];       // (elements outside K / M are zero)
-  const float mean = row_total(s1) / (float)p.K;
-  float s2 = 0.f;
-#pragma unroll
-  for (int u = 0; u < UNR; ++u)
-    if (kin[u])
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { const float d = (float)fa[u][j] - mean; s2 += d * d; }
-  const float rstd = 1.0f / sqrtf(row_total(s2) / (float)p.K + ln.eps);      // (same form as layernorm.hip)
+    for (int j = 0; j < 8; ++j) { const float x = (float)fa[u][j]; s1 += x; s2 += x * x; }     // (elements outside K / M are zero)
+  s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+  s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);                                   // over the four k-groups of the wave
+  if (g == 0) { rsum[wave][li] = s1; rsq[wave][li] = s2; }
+  __syncthreads();
+  const float mean = (rsum[0][li] + rsum[1][li] + rsum[2][li] + rsum[3][li]) / (float)p.K;
+  const float ex2 = (rsq[0][li] + rsq[1][li] + rsq[2][li] + rsq[3][li]) / (float)p.K;
+  const float rstd = 1.0f / sqrtf(fmaxf(ex2 - mean * mean, 0.f) + ln.eps);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int u = 0; u < UNR; ++u) {
