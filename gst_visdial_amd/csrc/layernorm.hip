@@ -335,8 +335,17 @@ __global__ __launch_bounds__(256) void colsum_batched_kernel(const gstvd_colsum_
   const int64_t col = (int64_t)(b - e.blk0) * 64 + cl, W = (int64_t)e.nvec * e.H;
   float a = 0.f;
   if (col < W) {
+    // eight independent loads in flight per thread: the embedding LayerNorm's 1024 partial rows used to be 256 dependent
+    // load -> add rounds per thread (118 us for a 48-block launch at the very end of backward)
     const float* src = e.partial + col;
-    for (int64_t k = rg; k < e.nblk; k += 4) a += src[k * e.stride];
+    float p8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int64_t k = rg;
+    for (; k + 28 < e.nblk; k += 32) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) p8[u] += src[(k + 4 * u) * e.stride];
+    }
+    for (; k < e.nblk; k += 4) a += src[k * e.stride];
+    a += ((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]));
   }
   red[rg][cl] = a;
   __syncthreads();
