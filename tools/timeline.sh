@@ -45,4 +45,6 @@ for t, d in pts:
     hist[lvl] += t - last; last = t; lvl += d
 print('time by number of kernels in flight (ms):', {k: round(v / 1e6, 2) for k, v in sorted(hist.items())})
 PY
+python3 tools/step_tail.py 2.6        # what runs after backward's last kernel
+python3 tools/step_tail.py 0.5 0 | tail -n +2 | sed "s/^/  [all]/"     # ... and everything in the last half millisecond
 rm -f $out/*/*kernel_trace.csv
