@@ -934,7 +934,8 @@ class Engine(object):
             # bf16: the three LayerNorms of a layer are folded into the Linears that read them (gstvd_gemv_ln) and the residual
             # adds into the epilogues of the Linears in front of them -- 8 launches per layer instead of 11.  `pre` = the
             # rows whose LayerNorm (parameters `lnp`) the next Linear still has to apply.
-            fuse = self.adt is torch.bfloat16 and Bn <= 16 and H <= 1024
+            fuse = (self.adt is torch.bfloat16 and Bn <= 16 and H <= 1024
+                    and bool(self.model.params.get("amd_decode_fuse_ln", True)))       # (the switch exists for the parity test)
             I_ = dc.intermediate_size
             pre, lnp = None, None
             for i in range(L):

@@ -99,6 +99,34 @@ def test_sampled_ids_equal_the_reference_under_the_same_uniforms():
     model.engine.close()
 
 
+def test_bf16_decode_step_with_folded_layernorms_matches_the_unfolded_plan_and_fp32():
+    """The bf16 decode step folds every LayerNorm into the Linear that reads it (gstvd_gemv_ln) and runs the single-query
+    attention kernel: the logits after a 10-token prefix (no sampling involved: max_seq_len = 1) equal those of the plan
+    with separate LayerNorm launches within bf16 rounding, and both sit at bf16 distance from the fp32-mode engine's."""
+    s = sc()
+    g = load_npz("tiny_train.npz")
+    gen = torch.Generator().manual_seed(3)
+    outs = {}
+    for name, prec, fuse in (("folded", "bf16", True), ("separate", "bf16", False), ("fp32", "fp32", True)):
+        model, params, cfg = s.build_tiny_model(prec, DEV, mode="vd_gen_val")
+        params["amd_decode_fuse_ln"] = fuse
+        params["amd_decode_graph"] = False
+        model.eval()
+        kw = _decode_kw(s, g)
+        Bn = kw["enc_input_ids"].shape[0]
+        prefix = torch.randint(104, 300, (Bn, 10), generator=torch.Generator().manual_seed(3)).to(DEV)
+        prefix[:, 0] = 101
+        seq = model.engine.sample(kw["enc_image_features"], kw["enc_image_spatials"], kw["enc_image_mask"], kw["enc_input_ids"],
+                                  kw["enc_segments"], kw["enc_attention_mask"], prefix, temperature=1.0, top_k=1, max_seq_len=1)
+        assert seq.shape == (Bn, 1)
+        outs[name] = model.engine.last["decode_logits"].clone()
+        model.engine.close()
+    scale = outs["fp32"].abs().max().item()
+    assert (outs["folded"] - outs["separate"]).abs().max().item() <= 2e-2 * max(1.0, scale)
+    assert (outs["folded"] - outs["fp32"]).abs().max().item() <= 0.1 * max(1.0, scale)
+    assert (outs["separate"] - outs["fp32"]).abs().max().item() <= 0.1 * max(1.0, scale)
+
+
 def test_top_p_decode_takes_the_unfused_eager_path():
     """top-p (not used by the reference's scripts, generate.py:138-141) is outside the fused sampling kernel: the filters run
     as torch ops step by step, nothing is captured, and the ids are those of the oracle's torch-op restatement."""
