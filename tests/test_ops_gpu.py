@@ -489,6 +489,32 @@ def test_gemm_grouped_column_sums():
     assert torch.allclose(gb, before + dy.float().sum(0), rtol=1e-5, atol=1e-3)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("nh,d,Lk", [(12, 64, 1), (12, 64, 19), (12, 64, 293), (3, 64, 1100), (8, 128, 37), (8, 128, 300), (4, 32, 77)])
+def test_single_query_attention_kernel(dtype, nh, d, Lk):
+    """The decode step's attention (Lq = 1: csrc/attention.hip attn_decode_kernel): one key up to more keys than a workgroup
+    scores in one round, every head width, masked keys, a strided KV cache and keys / values shared by groups of rows; LSE."""
+    o = ops()
+    Bn, G, Umax = 6, 3, Lk + 5
+    H = nh * d
+    q = rnd(Bn, H, dtype=dtype, seed=210)
+    kc, vc = rnd(2 * Umax, H, dtype=dtype, seed=211), rnd(2 * Umax, H, dtype=dtype, seed=212)     # two K/V rows of Umax slots each
+    km = torch.ones(2, Lk, device=DEV)
+    if Lk > 4:
+        km[1, Lk // 2:] = 0
+        km[0, 1] = 0
+    out = torch.full((Bn, H), float("nan"), device=DEV, dtype=dtype)
+    lse = torch.empty(Bn, nh, 1, device=DEV)
+    a = o.attn_desc(q, kc, vc, out, lse, km, Bn, nh, 1, Lk, d, mask_neg=-10000.0, kv_group=G, kv_bstride=Umax)
+    o.attn_fwd(a)
+    rep = lambda t: t.repeat_interleave(G, dim=0)
+    k4 = kc.view(2, Umax, nh, d)[:, :Lk].float()
+    v4 = vc.view(2, Umax, nh, d)[:, :Lk].float()
+    ref, lref = attn_ref(q.float().view(Bn, 1, nh, d), rep(k4), rep(v4), rep(km), False, -10000.0, 1 / math.sqrt(d), None)
+    check("attn_decode", out.view(Bn, 1, nh, d), ref, dtype, 2.0)
+    assert (lse.view(Bn, nh, 1) - lref).abs().max().item() <= (1e-4 if dtype == torch.float32 else 5e-2)
+
+
 @pytest.mark.parametrize("M,N,K", [(16, 768, 768), (16, 2304, 768), (5, 136, 200), (16, 3072, 1024), (3, 30528, 768)])
 def test_decode_layernorm_folded_into_the_linear(M, N, K):
     """gstvd_gemv_ln: C = epi(LN(A) . B^T) for the decode step's rows -- against LayerNorm (fp32 arithmetic on the bf16 rows,
@@ -555,6 +581,27 @@ def test_sample_topk_matches_the_torch_filters_and_inverse_cdf(dtype, V):
             assert abs(float(c[b, hi - 1] - c[b, lo]) if hi - 1 >= lo else 0.0) < 1e-5 and \
                 min(abs(float(c[b, lo]) - float(u[b])), abs(float(c[b, hi - 1]) - float(u[b]))) < 1e-5, (case, b)
         assert (got != want).sum().item() <= 1, case
+
+
+def test_sample_topk_degenerate_rows():
+    """Rows with a single candidate left, with every token banned, and k larger than the vocabulary: always a valid id, the
+    only candidate when there is one."""
+    o = ops()
+    V, Bn = 300, 4
+    logits = rnd(Bn, V, seed=77) * 3
+    banned = torch.zeros(Bn, V + 1, dtype=torch.bool, device=DEV)
+    banned[0, :V] = True; banned[0, 123] = False                 # one survivor
+    banned[1, :V] = True                                         # nothing left
+    u = torch.tensor([0.9, 0.5, 1e-7, 0.999999], device=DEV)
+    ids = torch.full((Bn,), -1, dtype=torch.long, device=DEV)
+    o.sample_topk(logits, 0.7, 7, u, ids, banned)
+    assert ids[0].item() == 123 and 0 <= ids[1].item() < V
+    o.sample_topk(logits, 1.0, 64, u, ids)                       # k = 64 of 300: rows 2 / 3 draw from the two ends of the CDF
+    top = torch.topk(logits.float(), 64, -1).indices
+    assert all(int(ids[b]) in set(top[b].tolist()) for b in range(Bn))
+    small = logits[:, :40].contiguous()
+    o.sample_topk(small, 1.0, 64, u, ids)                        # k beyond the vocabulary = no filter
+    assert ((ids >= 0) & (ids < 40)).all()
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
