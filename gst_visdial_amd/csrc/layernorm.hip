@@ -115,19 +115,31 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(LnP p) {
   const int H = (int)f.H;
   const DropKey dpre = make_drop(MODE == GSTVD_LN_RESID ? f.p_pre : 0.f, f.site_pre, f.rng);
   const DropKey dpost = make_drop(f.p_post, f.site_post, f.rng);
-  constexpr int NVP = (MODE == GSTVD_LN_EMBED) ? 4 : 3;      // partial vectors per block
-  f32x4 ag[NV], ab[NV], ax[NV], a4[NV];
+  constexpr int NVP = (MODE == GSTVD_LN_EMBED) ? 4 : 3;      // partial vectors per block that go to HBM
+  constexpr bool EXT = MODE == GSTVD_LN_EMBED && NV <= 4;    // embedding mode, H <= 1024: position slab + word strip fit the LDS
+  constexpr int NVL = EXT ? 5 : NVP;                         // vectors per wave that go through LDS (+ the block's position row)
+  f32x4 ag[NV], ab[NV], ax[NV], a4[NV], ap[NV];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) ag[i] = ab[i] = ax[i] = a4[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < NV; ++i) ag[i] = ab[i] = ax[i] = a4[i] = ap[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int64_t row0 = (int64_t)blockIdx.x * LN_BWD_RPB + wave * RW;
+  // Embedding mode, whole batches of rows per block (M = B * T, B a multiple of the block's rows): a block takes rows of ONE
+  // position t -- batch rows b0 .. b0 + RPB - 1 -- so their position-embedding gradients are summed in the block and reach
+  // dpos[t] as one atomic add per element and block instead of one per row (B-way contention on every address of a table of
+  // T rows: the kernel is the last one of backward, 0.1 ms for 4096 rows).
+  const int64_t nbat = (MODE == GSTVD_LN_EMBED && f.T > 0) ? f.M / f.T : 0;
+  const bool pos_block = EXT && nbat > 0 && nbat * f.T == f.M && nbat % LN_BWD_RPB == 0;
+  const int64_t bpt = pos_block ? nbat / LN_BWD_RPB : 1;     // blocks per position
+  const int64_t row0 = pos_block ? ((int64_t)(blockIdx.x % bpt) * LN_BWD_RPB + wave * RW) * f.T + blockIdx.x / bpt
+                                 : (int64_t)blockIdx.x * LN_BWD_RPB + wave * RW;
+  const int64_t rstep = pos_block ? f.T : 1;                 // distance between a wave's consecutive rows
+  float* wstrip = red + (int64_t)NW * NVL * H + (int64_t)wave * H;          // embedding mode: one row of dh per wave
   f32x4 xh[RW][NV], gy[RW][NV], dyv[RW][NV];
   float s1[RW] = {}, s2[RW] = {}, rstd[RW] = {};
   int64_t id[RW] = {}, tpos[RW] = {}, seg[RW] = {};
   bool rv[RW];
 #pragma unroll
   for (int j = 0; j < RW; ++j) {
-    const int64_t row = row0 + j;
+    const int64_t row = row0 + j * rstep;
     rv[j] = row < f.M;
     float locrow[5] = {0, 0, 0, 0, 0};
     float mean = 0.f;
@@ -157,7 +169,7 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(LnP p) {
   }
 #pragma unroll
   for (int j = 0; j < RW; ++j) {
-    const int64_t row = row0 + j;
+    const int64_t row = row0 + j * rstep;
     const float c1 = wave_sum(s1[j]) / (float)H, c2 = wave_sum(s2[j]) / (float)H;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -187,17 +199,34 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(LnP p) {
           // padded positions have an exactly-zero gradient (their keys are masked everywhere): skip their atomics,
           // which would all hit the [PAD] word row
           if (dh[0] != 0.f || dh[1] != 0.f || dh[2] != 0.f || dh[3] != 0.f) {
+            if (!pos_block) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              atomicAdd(p.dword + id[j] * f.H + c + e, dh[e]);
-              atomicAdd(p.dpos + tpos[j] * f.H + c + e, dh[e]);
+              for (int e = 0; e < 4; ++e) atomicAdd(p.dpos + tpos[j] * f.H + c + e, dh[e]);
+            } else {
+              ap[i] += dh;
             }
+          }
+          // word-embedding row: through the wave's LDS strip, so that one atomic instruction covers 64 CONSECUTIVE columns
+          // (two full 128-byte lines) instead of every fourth dword of a 1 KB span (eight lines a quarter used each)
+          if (EXT) {
+            *(f32x4*)(wstrip + c) = dh;
+          } else if (dh[0] != 0.f || dh[1] != 0.f || dh[2] != 0.f || dh[3] != 0.f) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(p.dword + id[j] * f.H + c + e, dh[e]);
           }
         }
       }
     }
+    if (EXT && rv[j]) {
+      // (same wave wrote the strip: LDS operations of one wave complete in order)
+      float* wrow = p.dword + id[j] * f.H;
+      for (int c = lane; c < H; c += 64) {
+        const float v = wstrip[c];
+        if (v != 0.f) atomicAdd(wrow + c, v);
+      }
+    }
   }
-  float* mine = red + (int64_t)wave * NVP * H;
+  float* mine = red + (int64_t)wave * NVL * H;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = lane * 4 + i * 256;
@@ -206,6 +235,7 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(LnP p) {
       *(f32x4*)(mine + H + c) = ab[i];
       *(f32x4*)(mine + 2 * H + c) = ax[i];
       if (NVP == 4) *(f32x4*)(mine + 3 * H + c) = a4[i];
+      if (NVL == 5) *(f32x4*)(mine + 4 * H + c) = ap[i];
     }
   }
   __syncthreads();
@@ -213,8 +243,19 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(LnP p) {
   for (int i = threadIdx.x * 4; i < NVP * H; i += NW * 256) {
     f32x4 a = *(const f32x4*)(red + i);
 #pragma unroll
-    for (int w = 1; w < NW; ++w) a += *(const f32x4*)(red + w * NVP * H + i);
+    for (int w = 1; w < NW; ++w) a += *(const f32x4*)(red + w * NVL * H + i);
     *(f32x4*)(out + i) = a;
+  }
+  if (NVL == 5 && pos_block) {                               // the block's position row: one atomic add per element
+    const int64_t t = (int64_t)(blockIdx.x / bpt) + f.pos_offset;
+    for (int i = threadIdx.x * 4; i < H; i += NW * 256) {
+      f32x4 a = *(const f32x4*)(red + 4 * H + i);
+#pragma unroll
+      for (int w = 1; w < NW; ++w) a += *(const f32x4*)(red + w * NVL * H + 4 * H + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (a[e] != 0.f) atomicAdd(p.dpos + t * f.H + i + e, a[e]);
+    }
   }
 }
 
@@ -417,9 +458,12 @@ static int ln_bwd_wide(const LnP& p, hipStream_t s) {       // 16 one-row waves 
 template <typename T, int MODE, int RW>
 static int ln_bwd_nv(const LnP& p, hipStream_t s) {
   dim3 grid((unsigned)gstvd_ln_bwd_blocks(p.f.M)), block(256);
-  size_t lds = (size_t)4 * (MODE == GSTVD_LN_EMBED ? 4 : 3) * p.f.H * sizeof(float);
+  // embedding mode: 4 slabs, or (H <= 1024) 5 slabs + the word strip per wave
+  size_t lds = (size_t)4 * (MODE == GSTVD_LN_EMBED ? (p.f.H <= 1024 ? 6 : 4) : 3) * p.f.H * sizeof(float);
   if (lds > 48 * 1024) {
-    static int rc8 = (int)hipFuncSetAttribute((const void*)ln_bwd_kernel<T, MODE, 8, RW>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4 * 2048 * 4);
+    static int rc8 = (int)hipFuncSetAttribute((const void*)ln_bwd_kernel<T, MODE, 8, RW>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4 * 2048 * 4)
+                   | (int)hipFuncSetAttribute((const void*)ln_bwd_kernel<T, MODE, 4, RW>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 6 * 1024 * 4)
+                   | (int)hipFuncSetAttribute((const void*)ln_bwd_kernel<T, MODE, 3, RW>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 6 * 768 * 4);
     if (rc8) return rc8;
   }
   if (p.f.H <= 256) hipLaunchKernelGGL((ln_bwd_kernel<T, MODE, 1, RW>), grid, block, lds, s, p);
