@@ -407,10 +407,22 @@ class Engine(object):
             ev = torch.cuda.Event()
             ev.record(src)
             self.aux.wait_event(ev)
-        with torch.cuda.stream(self.aux):
-            self.wgrads.flush()
+        if off == 0 and self.use_streams:
+            # the last slice, after backward's last kernel: the main stream has nothing left to do, so the slice's column
+            # reductions run there, beside its grouped weight-gradient launch on the auxiliary stream (which then waits for them)
+            with torch.cuda.stream(self.aux):
+                self.wgrads.flush()
             self.colsums.flush()
-            self.pipe.run_slice(off, self.pipe.hi)
+            ev = torch.cuda.Event()
+            ev.record(self.main)
+            self.aux.wait_event(ev)
+            with torch.cuda.stream(self.aux):
+                self.pipe.run_slice(off, self.pipe.hi)
+        else:
+            with torch.cuda.stream(self.aux):
+                self.wgrads.flush()
+                self.colsums.flush()
+                self.pipe.run_slice(off, self.pipe.hi)
         self.aux_busy = True
 
     # -- two HIP streams: the vision stream's skinny (M = B*37) kernels run beside the text stream's --------------
