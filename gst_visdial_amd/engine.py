@@ -23,6 +23,7 @@ the C ABI (`ops`).  Design points:
 Numerics: precision 'fp32' runs every GEMM on the exact-fp32 MFMA (parity gate: logits within 1e-4 of the
 oracle); 'bf16' stores activations/weights in bf16 with fp32 accumulation and fp32 LN/softmax/CE statistics.
 """
+import os
 import weakref
 
 import torch
@@ -722,8 +723,18 @@ class Engine(object):
         self.mark("dec")
         if self.rec and self.use_streams and self.pipe is None:
             self.tape.append(("t", self._flush_aux))      # backward: the decoder's gradients are complete here
+        kv_on_side = False
         if kv is None:
-            kv = self.lin(enc, "dec.ckv.w", "dec.ckv.b", 2 * L * H, H)
+            if self.use_streams and os.environ.get("GSTVD_KV_SIDE", "1") != "0":
+                # the cross-attention K/V of all layers (one 4688 x 18432 x 768 GEMM, 0.19 ms; its input gradient as much) goes
+                # to the side stream, idle since the encoder joined: it runs beside the decoder's embedding and the first layer's
+                # self-attention sub-layer, and in backward its input gradient beside what is left of the decoder's backward
+                self.sync("v", "t")
+                with self.on("v"):
+                    kv = self.lin(enc, "dec.ckv.w", "dec.ckv.b", 2 * L * H, H)
+                kv_on_side = True
+            else:
+                kv = self.lin(enc, "dec.ckv.w", "dec.ckv.b", 2 * L * H, H)
         y = self.embed("emb" if self.flat.dec_emb is self.flat.enc_emb else "demb", I["dec_ids"], None, Bn, U, c)
         for i in range(L):
             p = "d%d" % i
@@ -734,6 +745,8 @@ class Engine(object):
             ao = self.lin(ctx, p + ".ao.w", p + ".ao.b", H, H)
             y1 = self.ln(ao, y, p + ".ln1.w", p + ".ln1.b", H, c.hidden_dropout_prob, p + ".ao.b", eps)
             q = self.lin(y1, p + ".cq.w", p + ".cq.b", H, H)
+            if kv_on_side and i == 0:
+                self.sync("t", "v")               # the first cross-attention needs the K/V projection
             ctx = self.attn((q, 0), (kv, 2 * i * H), (kv, (2 * i + 1) * H), Bn, nh, U, S, d, I["emask"], False, -1e9,
                             c.attention_probs_dropout_prob, kv_group=kv_group)
             co = self.lin(ctx, p + ".co.w", p + ".co.b", H, H)
