@@ -79,7 +79,6 @@ SIGNATURES = {
     "gstvd_gemm_group_tile": (_i32, []),
     "gstvd_gemm_group_caps": (_i32, []),
     "gstvd_gemv_ln": (_i32, [C.POINTER(GemmDesc), _vp, _vp, _f32, _vp, _i64, _vp]),
-    "gstvd_debug_gemm_clock": (_i32, [_vp, _i32]),
     "gstvd_gemm_kernel_name": (_i32, [C.POINTER(GemmDesc), _i32, C.c_char_p, _i32]),
     "gstvd_gemm_grouped_kernel_name": (_i32, [_i32, _i32, _i32, _i32, C.c_char_p, _i32]),
     "gstvd_gemm_grouped": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp]),

@@ -56,6 +56,8 @@ def load_checkpoint(path, model, optimizer=None, cont=True, map_location="cpu"):
                 optimizer.load_state_dict(st)
             elif "state" in st and "param_groups" in st:          # written by the reference (or reference_format=True)
                 optimizer.import_reference_state(st)
+            elif "reference_state" in st:                         # a reference-format state saved before it was ever applied
+                optimizer.load_state_dict(st)
         return int(ck.get("iter_id", 0)) if isinstance(ck, dict) else 0
     enc = model.encoder
     own = enc.state_dict()

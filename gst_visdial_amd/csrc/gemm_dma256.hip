@@ -15,10 +15,18 @@
 static __device__ __attribute__((aligned(256))) char g_zero_page256[256];
 static constexpr int g_strip_w = 8;      // column-strip width of the tile order (measured 2 / 4 / 8: 31.3 / 30.7 / 30.5 us at 4096x3072x768)
 constexpr int NS256 = 5;    // ring depth: 5 x 32 KB = the whole 160 KB LDS of a CU
-// Diagnostic build only (GSTVD_GEMM_ST=3, never the default): shader-clock and 100 MHz wall-clock stamps around the K loop of
-// the first 512 workgroups, written to a buffer of their own -- in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz
-// (MI355X_MICROARCH.md, DVFS item 6).  gstvd_debug_gemm_clock() copies them out.
+// Timing ablations and in-kernel clock stamps exist only in the DIAGNOSTIC build of this file (-DGSTVD_DIAG ->
+// lib/libgstvd_hip_diag.so, `make diag`; loaded by tools/ only, never by gst_visdial_amd/_lib.py): several of them compute
+// wrong results on purpose, and no environment variable may be able to make the product library do that.
+#ifdef GSTVD_DIAG
+constexpr bool kDiag = true;
+// shader-clock and 100 MHz wall-clock stamps around the K loop of the first 512 workgroups (ST = 3), written to a buffer of their
+// own -- in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS item 6);
+// gstvd_debug_gemm_clock() copies them out
 static __device__ unsigned long long g_clk256[512 * 4];
+#else
+constexpr bool kDiag = false;
+#endif
 
 
 DEVFN int rm32_off(int row, int slot) { return row * 64 + ((slot ^ (((row >> 3) & 1) << 1)) << 4); }
@@ -83,14 +91,11 @@ struct Dma32 {
 
 // NIU = 16-column accumulator tiles per wave actually used (4: the full 256-wide tile; 3: a 192-wide tile inside the same
 // 256-wide LDS image -- N = 3072 then gives 16 x 16 = 256 tiles, one per CU, instead of 192 tiles on 256 CUs).
-// ST = stagger of the LDS-DMA issue inside a K-step.  All eight waves used to run the same sequence -- wait, barrier, issue
-// their 4 DMA pieces (~100+ cycles of issue each), read fragments, 32 MFMAs -- so both waves of a SIMD sat in the DMA-issue
-// phase together and the matrix pipe idled meanwhile (0.95 us per step against 0.43 us of MFMA work).  (ST = 1 / 2 / 5 were
-// measured in round 2 -- no gain, see DESIGN.md section 5 -- and are no longer instantiated; the code stays for the record.)  ST = 1: waves 0-3
-// (first wave of every SIMD) issue early as before, waves 4-7 issue their A pieces after half of their MFMAs and their B pieces
-// after the rest: one wave of a SIMD feeds the matrix pipe while its partner talks to the memory pipeline.  ST = 2: the late
-// half issues everything after its MFMAs.  The ring accounting is unchanged (a wave still issues LPS pieces per step, the
-// slot being filled was released by this step's barrier).
+// ST = K-step schedule: 0 the compiler's own order (DMA issue, then fragment reads two A fragments at a time in front of the
+// MFMAs that use them); 4 all twelve fragment reads first, then the DMA issue under their latency (GSTVD_GEMM_ST=4; correct
+// results, measured -4 % per step in isolation, nothing inside the step).  Staggered-issue schedules (round 2's ST = 1 / 2 / 5)
+// measured no gain and are gone (profiles/r02_gemm_kloop_study.txt).
+// PF < 0 (except -5, the ping-pong tile) and ST = 3 are timing-only ablations of the diagnostic build (kDiag).
 template <typename OT, bool AKM, bool BKM, int PF, int NIU = 4, int ST = 0>
 DEVFN void dma_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char* smem) {
   constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NS = NS256, NT = 512;
@@ -127,17 +132,18 @@ DEVFN void dma_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char
     ub.issue(s, p.K, smem + s * STAGE + A_BYTES, wave);
   }
   int slot = 0, fill = NS - 1;
+  static_assert(kDiag || ((PF == 0 || PF == -5) && (ST == 0 || ST == 4)), "timing ablations belong to the -DGSTVD_DIAG build");
+#ifdef GSTVD_DIAG
   unsigned long long clk0 = 0, rt0 = 0;
   if (ST == 3) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
   for (int64_t t = 0; t < nkt; ++t) {
     if (PF != -7) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPS) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    // PF = -7: like -1 but not even zero-page DMAs are issued inside the loop (pure LDS-read + MFMA + barrier loop)
-    // PF = -1 / -2 / -6 are timing-only ablations (wrong results): -1 = no DMA inside the loop, -2 = no LDS reads / MFMA,
-    // -6 = no epilogue
-    const bool late = (ST == 1 || ST == 2) && wave >= 4;       // wave-uniform
-    if ((ST == 4 || ST == 5) && PF != -2) {
+    // diagnostic build only -- PF = -1 / -2 / -6 / -7 / -8 are timing-only ablations (wrong results): -1 = zero-page DMAs
+    // inside the loop, -7 = no DMA instruction at all, -2 = no LDS reads / MFMA, -8 = MFMAs on stale registers, -6 = no epilogue
+    if (ST == 4 && PF != -2) {
       // fragment reads first, all twelve of them (48 VGPRs): the compiler's own schedule reads two A fragments at a time right
       // before the eight MFMAs that use them, which leaves the matrix pipe waiting on LDS latency eight times per step
       // (in-kernel stamps: 1617 cycles per step for 1024 cycles of MFMA work with the DMA switched off).  Then the DMA issue,
@@ -150,33 +156,18 @@ DEVFN void dma_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char
 #pragma unroll
       for (int i = 0; i < MI; ++i) fa[i] = frag32<BM, AKM>(cA, wm * WTM + i * 16, lane);
       __builtin_amdgcn_sched_barrier(0);
-      // ST = 5: reads first AND the second wave of every SIMD (waves 4-7) issues its DMA in the middle / at the end of its MFMAs,
-      // so that one wave of the SIMD starts feeding the matrix pipe as soon as its fragments arrive while the other one spends
-      // its first ~260 cycles issuing DMA
-      const bool late5 = ST == 5 && wave >= 4;
       if (PF == -1) {
         ua.issue(1 << 20, p.K, smem + fill * STAGE, wave);
         ub.issue(1 << 20, p.K, smem + fill * STAGE + A_BYTES, wave);
-      } else if (!late5) {
+      } else {
         ua.issue(t + NS - 1, p.K, smem + fill * STAGE, wave);
         ub.issue(t + NS - 1, p.K, smem + fill * STAGE + A_BYTES, wave);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        if (ST == 5 && i == MI / 2) {
-          __builtin_amdgcn_sched_barrier(0);
-          if (late5 && PF != -1) ua.issue(t + NS - 1, p.K, smem + fill * STAGE, wave);
-          __builtin_amdgcn_sched_barrier(0);
-        }
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = mfma_bf16_k32(fb[j], fa[i], acc[i][j]);
-      }
-      if (ST == 5) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (late5 && PF != -1) ub.issue(t + NS - 1, p.K, smem + fill * STAGE + A_BYTES, wave);
-        __builtin_amdgcn_sched_barrier(0);
-      }
       slot = (slot + 1 == NS) ? 0 : slot + 1;
       fill = (fill + 1 == NS) ? 0 : fill + 1;
       continue;
@@ -185,7 +176,7 @@ DEVFN void dma_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char
     } else if (PF == -1) {
       ua.issue(1 << 20, p.K, smem + fill * STAGE, wave);      // zero-page DMAs keep the vmcnt bookkeeping identical
       ub.issue(1 << 20, p.K, smem + fill * STAGE + A_BYTES, wave);
-    } else if (!late) {
+    } else {
       ua.issue(t + NS - 1, p.K, smem + fill * STAGE, wave);
       ub.issue(t + NS - 1, p.K, smem + fill * STAGE + A_BYTES, wave);
     }
@@ -203,33 +194,22 @@ DEVFN void dma_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char
       for (int j = 0; j < NI; ++j) fb[j] = frag32<BN, BKM>(cB, wn * WTN + j * 16, lane);
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
-        if (ST == 1 && i == MI / 2) {
-          __builtin_amdgcn_sched_barrier(0);
-          if (late) ua.issue(t + NS - 1, p.K, smem + fill * STAGE, wave);
-          __builtin_amdgcn_sched_barrier(0);
-        }
         const bf16x8 fa = frag32<BM, AKM>(cA, wm * WTM + i * 16, lane);
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = mfma_bf16_k32(fb[j], fa, acc[i][j]);
-      }
-      if (ST == 1 || ST == 2) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (late) {
-          if (ST == 2) ua.issue(t + NS - 1, p.K, smem + fill * STAGE, wave);
-          ub.issue(t + NS - 1, p.K, smem + fill * STAGE + A_BYTES, wave);
-        }
-        __builtin_amdgcn_sched_barrier(0);
       }
     }
     slot = (slot + 1 == NS) ? 0 : slot + 1;
     fill = (fill + 1 == NS) ? 0 : fill + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef GSTVD_DIAG
   if (ST == 3 && tid == 0 && wg < 512) {
     g_clk256[wg * 4 + 0] = __builtin_amdgcn_s_memtime() - clk0;
     g_clk256[wg * 4 + 1] = __builtin_amdgcn_s_memrealtime() - rt0;
     g_clk256[wg * 4 + 2] = (unsigned long long)nkt;
   }
+#endif
 
   const int g = lane >> 4, li = lane & 15;
   const DropKey dk = make_drop((p.epi & GSTVD_EPI_DROPOUT) ? p.p : 0.f, p.site, p.rng);
@@ -549,26 +529,35 @@ template <typename OT, bool AKM, bool BKM>
 static int launch256(const GemmP& p, int64_t batch, int niu, hipStream_t s) {
   auto k0 = gemm_dma256_kernel<OT, AKM, BKM, 0>;
   auto k3 = gemm_dma256_kernel<OT, AKM, BKM, 0, 3>;
+  auto p0 = gemm_dma256_kernel<OT, AKM, BKM, 0, 4, 4>;
+  auto p3 = gemm_dma256_kernel<OT, AKM, BKM, 0, 3, 4>;
+  auto ke = gemm_dma256_kernel<OT, AKM, BKM, -5>;
+  static int attr_rc = ensure_lds(k0, LDS256) | ensure_lds(k3, LDS256) | ensure_lds(ke, LDS256) | ensure_lds(p0, LDS256) |
+                       ensure_lds(p3, LDS256);
+  if (attr_rc) return attr_rc;
+  // schedule selectors of the PRODUCT build -- every value computes correct results: GSTVD_GEMM_ST 0 / 4 (K-step schedule),
+  // GSTVD_GEMM_PP=1 the ping-pong tile (round 2's GSTVD_GEMM_ABLATE=5)
+  static const int st_env = [] { const char* e = getenv("GSTVD_GEMM_ST"); return e ? atoi(e) : 0; }();
+  static const int pp = [] { const char* e = getenv("GSTVD_GEMM_PP"); return e ? atoi(e) : 0; }();
+  int abl = pp ? 5 : 0, st = st_env == 4 ? 4 : 0;
+#ifdef GSTVD_DIAG
   auto c0 = gemm_dma256_kernel<OT, AKM, BKM, 0, 4, 3>;
   auto c1 = gemm_dma256_kernel<OT, AKM, BKM, -1, 4, 3>;
   auto c2 = gemm_dma256_kernel<OT, AKM, BKM, -2, 4, 3>;
   auto c7 = gemm_dma256_kernel<OT, AKM, BKM, -7, 4, 3>;
   auto c8 = gemm_dma256_kernel<OT, AKM, BKM, -8, 4, 3>;
-  auto p0 = gemm_dma256_kernel<OT, AKM, BKM, 0, 4, 4>;
-  auto p3 = gemm_dma256_kernel<OT, AKM, BKM, 0, 3, 4>;
   auto p1 = gemm_dma256_kernel<OT, AKM, BKM, -1, 4, 4>;
-
   auto ka = gemm_dma256_kernel<OT, AKM, BKM, -1>;
   auto kb = gemm_dma256_kernel<OT, AKM, BKM, -2>;
-  auto ke = gemm_dma256_kernel<OT, AKM, BKM, -5>;
   auto kf = gemm_dma256_kernel<OT, AKM, BKM, -6>;
-  static int attr_rc = ensure_lds(k0, LDS256) | ensure_lds(k3, LDS256) | ensure_lds(ka, LDS256) | ensure_lds(kb, LDS256) |
-                       ensure_lds(ke, LDS256) | ensure_lds(kf, LDS256) | 
-                       ensure_lds(c0, LDS256) | ensure_lds(c1, LDS256) | ensure_lds(c2, LDS256) | ensure_lds(c7, LDS256) | ensure_lds(c8, LDS256) |
-                       ensure_lds(p0, LDS256) | ensure_lds(p3, LDS256) | ensure_lds(p1, LDS256);
-  if (attr_rc) return attr_rc;
-  static const int abl = [] { const char* e = getenv("GSTVD_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
-  static const int st = [] { const char* e = getenv("GSTVD_GEMM_ST"); return e ? atoi(e) : 0; }();
+  static int diag_rc = ensure_lds(c0, LDS256) | ensure_lds(c1, LDS256) | ensure_lds(c2, LDS256) | ensure_lds(c7, LDS256) |
+                       ensure_lds(c8, LDS256) | ensure_lds(p1, LDS256) | ensure_lds(ka, LDS256) | ensure_lds(kb, LDS256) |
+                       ensure_lds(kf, LDS256);
+  if (diag_rc) return diag_rc;
+  static const int diag_abl = [] { const char* e = getenv("GSTVD_DIAG_ABLATE"); return e ? atoi(e) : 0; }();
+  if (diag_abl) abl = diag_abl;
+  if (st_env == 3) st = 3;
+#endif
   const int bnu = (niu == 3 && abl == 0) ? 192 : 256;
   const int ntm = (int)((p.M + 255) / 256), ntn = (int)((p.N + bnu - 1) / bnu);
   // producer / consumer form: measured -7 % per launch on single-round grids (4096x3072x768 33.8 -> 31.3 us, per K-step 0.82 ->
@@ -583,9 +572,15 @@ static int launch256(const GemmP& p, int64_t batch, int niu, hipStream_t s) {
     GSTVD_LAUNCH_CHECK();
     return 0;
   }
-  GSTVD_LAUNCH(st == 4 ? (abl == 1 ? p1 : bnu == 192 ? p3 : p0) : st == 3 ? (abl == 1 ? c1 : abl == 2 ? c2 : abl == 7 ? c7 : abl == 8 ? c8 : c0) : abl == 1 ? ka : abl == 2 ? kb : abl == 5 ? ke : abl == 6 ? kf :
-                     (bnu == 192 ? k3 : k0),
-                     dim3((unsigned)(ntm * ntn), (unsigned)batch), dim3(512), LDS256, s, p, ntn, ntm * ntn);
+  auto kern = st == 4 ? (bnu == 192 ? p3 : p0) : abl == 5 ? ke : (bnu == 192 ? k3 : k0);
+#ifdef GSTVD_DIAG
+  if (st == 4 && abl == 1) kern = p1;
+  else if (st == 3) kern = abl == 1 ? c1 : abl == 2 ? c2 : abl == 7 ? c7 : abl == 8 ? c8 : c0;
+  else if (abl == 1) kern = ka;
+  else if (abl == 2) kern = kb;
+  else if (abl == 6) kern = kf;
+#endif
+  GSTVD_LAUNCH(kern, dim3((unsigned)(ntm * ntn), (unsigned)batch), dim3(512), LDS256, s, p, ntn, ntm * ntn);
   GSTVD_LAUNCH_CHECK();
   return 0;
 }
@@ -645,7 +640,7 @@ static int grouped256(const gstvd_gemm_t* tab, const int* off, int nprob, int to
   auto k4 = gemm_dma256_grouped_kernel<OT, AKM, BKM, 0, 4>;
   static int attr_rc = ensure_lds(k0, LDS256) | ensure_lds(k4, LDS256);
   if (attr_rc) return attr_rc;
-  static const int st = [] { const char* e = getenv("GSTVD_GEMM_ST"); return e ? atoi(e) : 0; }();
+  static const int st = [] { const char* e = getenv("GSTVD_GEMM_ST"); return (e && atoi(e) == 4) ? 4 : 0; }();
   // tiles per XCD chunk = 2^chs (default 8: measured best of 1..128 inside the step); GSTVD_GROUP_CHUNK_LOG2 overrides for tuning runs
   static const int chs = [] { const char* e = getenv("GSTVD_GROUP_CHUNK_LOG2"); const int v = e ? atoi(e) : 3; return v < 0 ? 0 : (v > 10 ? 10 : v); }();
   // weight gradients are long-K problems (K = rows of the batch): the producer / consumer tile gains ~0.08 us on every one of
@@ -669,7 +664,7 @@ extern "C" int gstvd_gemm_group_tile(void) { return 256; }
 extern "C" int32_t gstvd_gemm_group_caps(void) {
   const char* e = getenv("GSTVD_GEMM_PC");
   const char* t = getenv("GSTVD_GEMM_ST");
-  const bool pc = (e ? atoi(e) : 1) != 0 && (t ? atoi(t) : 0) == 0;
+  const bool pc = (e ? atoi(e) : 1) != 0 && (t ? atoi(t) : 0) != 4;
   return pc ? 1 : 0;
 }
 
@@ -692,11 +687,13 @@ extern "C" int gstvd_gemm_grouped_kernel_name(int32_t dtype_in, int32_t dtype_ou
   return 0;
 }
 
+#ifdef GSTVD_DIAG
 extern "C" int gstvd_debug_gemm_clock(uint64_t* out_host, int32_t n_words) {
   if (!out_host || n_words <= 0 || n_words > 512 * 4) return GSTVD_E_SHAPE;
   hipError_t e = hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_clk256), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost);
   return e == hipSuccess ? 0 : (int)e;
 }
+#endif
 
 extern "C" int gstvd_gemm_grouped(const gstvd_gemm_t* table_dev, const int32_t* tile_off_dev, int64_t nprob, int64_t total_tiles,
                                   int32_t dtype_in, int32_t dtype_out, int32_t a_kmajor, int32_t b_kmajor, gstvd_stream_t stream) {

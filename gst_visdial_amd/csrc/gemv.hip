@@ -45,7 +45,8 @@ __global__ __launch_bounds__(NW * 64) void gemv16_kernel(GemmP p) {
   if (m >= p.M || n >= p.N) return;
   f32x4 v = acc * p.alpha;
   if (p.epi & GSTVD_EPI_BIAS) v += *(const f32x4*)(p.bias + n);
-  if (p.epi & GSTVD_EPI_ADD) v += ld4((const bf16*)p.addend + m * p.ldadd + n);
+  if (p.epi & GSTVD_EPI_ADD)        // the addend has the OUTPUT's type, as in the tiled kernels' epilogue (gemm_epilogue_tile)
+    v += F32OUT ? ld4((const float*)p.addend + m * p.ldadd + n) : ld4((const bf16*)p.addend + m * p.ldadd + n);
   if (p.epi & GSTVD_EPI_GELU) {
     f32x4 d;
 #pragma unroll
@@ -135,7 +136,8 @@ __global__ __launch_bounds__(256) void gemv16_ln_kernel(GemmP p, LnIn ln) {
   if (m >= p.M || n >= p.N) return;
   f32x4 v = acc * p.alpha;
   if (p.epi & GSTVD_EPI_BIAS) v += *(const f32x4*)(p.bias + n);
-  if (p.epi & GSTVD_EPI_ADD) v += ld4((const bf16*)p.addend + m * p.ldadd + n);
+  if (p.epi & GSTVD_EPI_ADD)        // the addend has the OUTPUT's type, as in the tiled kernels' epilogue (gemm_epilogue_tile)
+    v += F32OUT ? ld4((const float*)p.addend + m * p.ldadd + n) : ld4((const bf16*)p.addend + m * p.ldadd + n);
   if (p.epi & GSTVD_EPI_GELU) {
     f32x4 d;
 #pragma unroll

@@ -280,7 +280,9 @@ def device_streams(device):
     """ONE (vision, auxiliary) stream pair per device for every engine of the process.  torch hands out pool streams
     round-robin over 32 slots; a pair per Engine meant that after ~16 models (a test session, a checkpoint sweep) new
     engines aliased older engines' streams and the capture stream."""
-    key = torch.device(device).index or 0
+    key = torch.device(device).index
+    if key is None:                     # an index-less 'cuda': the CURRENT device, not device 0
+        key = torch.cuda.current_device()
     if key not in _DEVICE_STREAMS:
         _DEVICE_STREAMS[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
     return _DEVICE_STREAMS[key]
@@ -290,9 +292,12 @@ class Engine(object):
     def __init__(self, model):
         # weak: the model owns the engine, not the other way round -- no reference cycle, so dropping the model frees the
         # flat buffers, the arena and any captured decode sessions by reference counting, not at some later GC pass
-        self._model_ref = weakref.ref(model)
-        self.enc_cfg, self.dec_cfg = model.encoder.config, model.decoder.config
-        prec = model.params.get("amd_precision", "bf16")
+        self._setup(weakref.ref(model), model.encoder.config, model.decoder.config, model.params)
+
+    def _setup(self, model_ref, enc_cfg, dec_cfg, params):
+        self._model_ref = model_ref
+        self.enc_cfg, self.dec_cfg = enc_cfg, dec_cfg
+        prec = params.get("amd_precision", "bf16")
         if prec not in ("bf16", "fp32"):
             raise GstvdError("params['amd_precision'] must be 'bf16' or 'fp32'")
         self.precision = prec
@@ -308,7 +313,7 @@ class Engine(object):
         self.accumulate, self.written = False, set()
         self.stats = {}
         self._validate = True
-        self.use_streams = bool(model.params.get("amd_streams", True))
+        self.use_streams = bool(params.get("amd_streams", True))
         self.tag = "t"
 
     @property
@@ -317,6 +322,21 @@ class Engine(object):
         if m is None:
             raise GstvdError("the EncoderDecoderModel this engine belonged to is gone")
         return m
+
+    def __deepcopy__(self, memo):
+        """copy.deepcopy(model) copies the module tree; the copy's `engine` attribute must serve the COPY, not stay bound
+        (through the weak reference) to the original.  The owner is already in `memo` when its attributes are copied."""
+        import copy
+        orig = self._model_ref()
+        owner = memo.get(id(orig))
+        if owner is None:
+            raise GstvdError("an Engine is copied with its EncoderDecoderModel (copy.deepcopy(model)), not on its own")
+        # (the owner is still being filled in at this point: take the configs / params through `memo`, which hands out the
+        # very objects the copied module tree gets)
+        new = Engine.__new__(Engine)
+        new._setup(weakref.ref(owner), copy.deepcopy(self.enc_cfg, memo), copy.deepcopy(self.dec_cfg, memo),
+                   copy.deepcopy(orig.params, memo))
+        return new
 
     def close(self):
         """Drop captured decode sessions (hipGraphs + their private pool) now."""
@@ -340,7 +360,13 @@ class Engine(object):
         if self.arena is None or self.arena.device != device:
             self._decode_sessions.clear()
             self.arena = Arena(device)
-            self.rng = ops.Rng(device, seed=int(self.model.params.get("amd_seed", 0)))
+            seed = int(self.model.params.get("amd_seed", 0))
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and self.model.params.get("amd_seed_per_rank", True):
+                # one mask stream per data-parallel rank, like the per-device generators of the reference's DataParallel
+                # replicas (train_gen.py:295); params['amd_seed_per_rank'] = False restores one shared stream
+                seed = ops.rank_seed(seed, dist.get_rank())
+            self.rng = ops.Rng(device, seed=seed)
             self.anchor = torch.zeros(1, device=device, requires_grad=True)
             self.side, self.aux = device_streams(device)
             self.aux_busy = False
@@ -367,8 +393,14 @@ class Engine(object):
     def act(self, M, N):
         return Act(self.buf(M, N), M, N)
 
-    def site(self):
+    def site(self, label=None, p=0.0, kind=None, shape=None, **extra):
+        """Next dropout site of the step.  Sites are numbered in issue order; `site_log[label]` keeps what a checker needs to
+        regenerate the site's keep mask with gstvd_dropout_mask (tests: the oracle is run with exactly these masks)."""
         self._site += 1
+        if label is not None and self.train:
+            if label in self.site_log:
+                raise GstvdError("internal: dropout site label used twice in one step: " + label)
+            self.site_log[label] = dict(site=self._site, p=float(p), kind=kind, shape=shape, **extra)
         return self._site
 
     def grad_slot(self, name):
@@ -512,7 +544,7 @@ class Engine(object):
         y = self.act(M, H)
         kw = dict(mode=LN_RESID, dtype=ops.dt(x.t), M=M, H=H, gamma=self.Pv[g], beta=self.Pv[b],
                   mean=self.vec(M), rstd=self.vec(M), eps=eps, x=x.t, res=res.t if res is not None else None, y=y.t,
-                  p_pre=p_pre if self.train else 0.0, site_pre=self.site(), rng=self.rng)
+                  p_pre=p_pre if self.train else 0.0, site_pre=self.site(g[:-2], p_pre, "rows", (M, H)), rng=self.rng)
         ops.ln_fwd(**kw)
         self.push(lambda: self._ln_bwd(kw, x, res, y, g, b, H, bias_name))
         return y
@@ -541,14 +573,16 @@ class Engine(object):
         self._colsums(partial, nblk, H, [g, b, bias_name])
         x.bias_done = bias_name is not None
 
-    def embed(self, prefix, ids, segs, Bn, T, cfg, pos_offset=0):
+    def embed(self, prefix, ids, segs, Bn, T, cfg, pos_offset=0, label=None, p_drop=None):
         M, H = Bn * T, cfg.hidden_size
+        if p_drop is None:
+            p_drop = cfg.hidden_dropout_prob
         y = self.act(M, H)
         kw = dict(mode=LN_EMBED, dtype=ops.dt(y.t), M=M, H=H, gamma=self.Pv[prefix + ".ln.w"], beta=self.Pv[prefix + ".ln.b"],
                   mean=self.vec(M), rstd=self.vec(M), eps=1e-12, y=y.t, ids=ids, segs=segs, T=T,
                   type_vocab=cfg.type_vocab_size, word=self.Pv[prefix + ".word"], pos=self.Pv[prefix + ".pos"],
                   tt=self.Pv[prefix + ".tt"], tt_ext=self.Pv[prefix + ".tte"],
-                  p_post=cfg.hidden_dropout_prob if self.train else 0.0, site_post=self.site(), rng=self.rng,
+                  p_post=p_drop if self.train else 0.0, site_post=self.site(label, p_drop, "rows", (M, H)), rng=self.rng,
                   pos_offset=pos_offset)
         ops.ln_fwd(**kw)
         self.push(lambda: self._embed_bwd(kw, prefix, y, M, H))
@@ -577,7 +611,7 @@ class Engine(object):
         kw = dict(mode=LN_IMAGE, dtype=ops.dt(x.t), M=M, H=H, gamma=self.Pv["vemb.ln.w"], beta=self.Pv["vemb.ln.b"],
                   mean=self.vec(M), rstd=self.vec(M), eps=1e-12, x=x.t, y=y.t, loc=loc, w_loc=self.Pv["vemb.loc.w"],
                   b_loc=self.Pv["vemb.loc.b"], p_post=cfg.hidden_dropout_prob if self.train else 0.0,
-                  site_post=self.site(), rng=self.rng)
+                  site_post=self.site("vemb", cfg.hidden_dropout_prob, "rows", (M, H)), rng=self.rng)
         ops.ln_fwd(**kw)
         self.push(lambda: self._img_embed_bwd(kw, x, y, loc, M, H))
         return y
@@ -593,13 +627,14 @@ class Engine(object):
         gw, acc = self.grad_slot("vemb.loc.w")
         ops.locgrad(x.g, loc, M, H, gw, acc)
 
-    def attn(self, q, k, v, Bn, nh, Lq, Lk, d, key_mask, causal, neg, p, kv_group=1, kv_bstride=0):
+    def attn(self, q, k, v, Bn, nh, Lq, Lk, d, key_mask, causal, neg, p, kv_group=1, kv_bstride=0, label=None):
         (qa, qc), (ka, kc), (va, vc) = q, k, v
         Hh = nh * d
         o = self.act(Bn * Lq, Hh)
         lse = self.vec(Bn * nh * Lq)
         a = ops.attn_desc(qa.t[:, qc:qc + Hh], ka.t[:, kc:kc + Hh], va.t[:, vc:vc + Hh], o.t, lse, key_mask, Bn, nh, Lq, Lk, d,
-                          causal=causal, mask_neg=neg, drop_p=p if self.train else 0.0, site=self.site(), rng=self.rng,
+                          causal=causal, mask_neg=neg, drop_p=p if self.train else 0.0,
+                          site=self.site(label, p, "attn", (Bn, nh, Lq, (Lk + 3) // 4 * 4), Lk=Lk), rng=self.rng,
                           kv_group=kv_group, kv_bstride=kv_bstride)
         ops.attn_fwd(a)
         self.push(lambda: self._attn_bwd(a, q, k, v, o, Bn, nh, Lq, Hh))
@@ -618,7 +653,7 @@ class Engine(object):
     def self_block(self, p, x, Bn, L, H, nh, key_mask, pa, ph, causal=False):
         """QKV -> attention -> output dense -> dropout -> LN(+x)   (vilbert_dialog.py:380-431)"""
         qkv = self.lin(x, p + ".qkv.w", p + ".qkv.b", 3 * H, H)
-        ctx = self.attn((qkv, 0), (qkv, H), (qkv, 2 * H), Bn, nh, L, L, H // nh, key_mask, causal, -10000.0, pa)
+        ctx = self.attn((qkv, 0), (qkv, H), (qkv, 2 * H), Bn, nh, L, L, H // nh, key_mask, causal, -10000.0, pa, label=p + ".attn")
         ao = self.lin(ctx, p + ".ao.w", p + ".ao.b", H, H)
         return self.ln(ao, x, p + ".ln1.w", p + ".ln1.b", H, ph, p + ".ao.b")
 
@@ -647,10 +682,10 @@ class Engine(object):
         self.sync("t", "v")
         self.sync("v", "t")
         ctx1 = self.attn((qkv2, 0), (qkv1, Hb), (qkv1, 2 * Hb), Bn, nh, T, R, d, I["vmask"], False, -10000.0,
-                         c.v_attention_probs_dropout_prob)
+                         c.v_attention_probs_dropout_prob, label=p + ".attn1")
         with self.on("v"):
             ctx2 = self.attn((qkv1, 0), (qkv2, Hb), (qkv2, 2 * Hb), Bn, nh, R, T, d, I["tmask"], False, -10000.0,
-                             c.attention_probs_dropout_prob)
+                             c.attention_probs_dropout_prob, label=p + ".attn2")
             hv = self.lin(ctx2, p + ".d1.w", p + ".d1.b", Hv, Hb)
             av = self.ln(hv, xv, p + ".ln1.w", p + ".ln1.b", Hv, c.v_hidden_dropout_prob, p + ".d1.b")
             ov = self.ffn_block(p, av, Hv, c.v_intermediate_size, c.v_hidden_dropout_prob, ".vfi", ".vfo", ".vln")
@@ -663,7 +698,7 @@ class Engine(object):
         """BertModel.forward for enc_dec (vilbert_dialog.py:1325-1407); poolers / cls heads are dead and skipped."""
         c = self.enc_cfg
         Bn, T, R = I["B"], I["T"], I["R"]
-        xt = self.embed("emb", I["ids"], I["segs"], Bn, T, c)
+        xt = self.embed("emb", I["ids"], I["segs"], Bn, T, c, label="emb.enc")
         f = Act(I["feats"], Bn * R, c.v_feature_size)
         self.sync("v", "t")                   # fork: the vision stream starts once the inputs are staged
         with self.on("v"):
@@ -696,7 +731,7 @@ class Engine(object):
         self.mark("vlf")
         enc = self.act(Bn * S, H)
         p = 0.1 if self.train else 0.0
-        sv, st = self.site(), self.site()
+        sv, st = self.site("vlf.v", 0.1, "rows", (Bn * R, H)), self.site("vlf.l", 0.1, "rows", (Bn * T, H))
         e3 = enc.t.view(Bn, S, H)
         ops.gemm(xv.t, self.W["vlf.v.w"], e3[:, :R], R, H, Hv, bias=self.Pv["vlf.v.b"], batch=Bn, sA=R * Hv, sC=S * H,
                  lda=Hv, ldc=H, drop_p=p, site=sv, rng=self.rng)
@@ -735,20 +770,24 @@ class Engine(object):
                 kv_on_side = True
             else:
                 kv = self.lin(enc, "dec.ckv.w", "dec.ckv.b", 2 * L * H, H)
-        y = self.embed("emb" if self.flat.dec_emb is self.flat.enc_emb else "demb", I["dec_ids"], None, Bn, U, c)
+        shared = self.flat.dec_emb is self.flat.enc_emb
+        # the embedding MODULE's own dropout: with the shared module of train_gen.py:293 that is the ENCODER config's
+        # hidden_dropout_prob (vilbert_dialog.py:321), whoever calls it (tests/golden/tiny_train_dropout.npz)
+        y = self.embed("emb" if shared else "demb", I["dec_ids"], None, Bn, U, c, label="emb.dec",
+                       p_drop=self.enc_cfg.hidden_dropout_prob if shared else None)
         for i in range(L):
             p = "d%d" % i
             self.mark(("d", i))
             qkv = self.lin(y, p + ".qkv.w", p + ".qkv.b", 3 * H, H)
             ctx = self.attn((qkv, 0), (qkv, H), (qkv, 2 * H), Bn, nh, U, U, d, I["dmask"], True, -10000.0,
-                            c.attention_probs_dropout_prob)
+                            c.attention_probs_dropout_prob, label=p + ".attn")
             ao = self.lin(ctx, p + ".ao.w", p + ".ao.b", H, H)
             y1 = self.ln(ao, y, p + ".ln1.w", p + ".ln1.b", H, c.hidden_dropout_prob, p + ".ao.b", eps)
             q = self.lin(y1, p + ".cq.w", p + ".cq.b", H, H)
             if kv_on_side and i == 0:
                 self.sync("t", "v")               # the first cross-attention needs the K/V projection
             ctx = self.attn((q, 0), (kv, 2 * i * H), (kv, (2 * i + 1) * H), Bn, nh, U, S, d, I["emask"], False, -1e9,
-                            c.attention_probs_dropout_prob, kv_group=kv_group)
+                            c.attention_probs_dropout_prob, kv_group=kv_group, label=p + ".xattn")
             co = self.lin(ctx, p + ".co.w", p + ".co.b", H, H)
             y2 = self.ln(co, y1, p + ".ln2.w", p + ".ln2.b", H, c.hidden_dropout_prob, p + ".co.b", eps)
             a = self.lin(y2, p + ".fi.w", p + ".fi.b", c.intermediate_size, H, gelu=True)
@@ -804,6 +843,7 @@ class Engine(object):
         self.tag = "t"
         self.main = torch.cuda.current_stream()
         self._site = 0
+        self.site_log = {}
         self.train = bool(self.model.training)
         if self.train:
             self.rng.advance()

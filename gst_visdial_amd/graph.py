@@ -49,6 +49,7 @@ def _active_collectives():
         return None
 
 
+_WARNED_TIMER = False
 LAST_QUIESCE = [None]      # how the most recent capture waited for c10d's watchdog: "no-process-group" | "drained" | "timer"
 
 
@@ -63,14 +64,23 @@ def _quiesce(timeout):
     event of the capturing stream: the capture is invalidated (hipErrorStreamCaptureInvalidated) and the watchdog's own
     exception aborts the process (round 1: 1 run in 6).  Deterministic form: (1) device idle -> every eager collective has
     completed; (2) wait until the flight recorder reports no un-retired collective, i.e. the watchdog has popped them all.
-    Without the recorder (TORCH_NCCL_TRACE_BUFFER_SIZE unset before init_process_group) fall back to five watchdog periods."""
+    Without the recorder (TORCH_NCCL_TRACE_BUFFER_SIZE unset before init_process_group) fall back to a 2 s sleep (twenty watchdog periods, round 1's validated wait) and warn once."""
     torch.cuda.synchronize()
     if not dist_alive():
         return "no-process-group"
     t0 = time.time()
     n = _active_collectives()
     if n is None:
-        time.sleep(0.5)
+        # no flight recorder (TORCH_NCCL_TRACE_BUFFER_SIZE was not set before init_process_group, or this torch's
+        # _dump_nccl_trace differs): round 1's validated wait -- 20 watchdog periods; 0.5 s let the 1-in-6 abort come back
+        global _WARNED_TIMER
+        if not _WARNED_TIMER:
+            _WARNED_TIMER = True
+            import warnings
+            warnings.warn("gst_visdial_amd.graph: c10d flight recorder unavailable -- waiting 2 s before the stream capture "
+                          "instead of draining the watchdog deterministically; call graph.enable_watchdog_introspection() "
+                          "before init_process_group")
+        time.sleep(2.0)
         return "timer"
     while n > 0:
         if time.time() - t0 > timeout:

@@ -108,6 +108,12 @@ def gemm_kernel_symbol(d, splits=1):
     return name
 
 
+def rank_seed(seed, rank):
+    """Dropout seed of data-parallel rank `rank`: every nn.DataParallel replica of the reference draws its masks from its own
+    device's generator (train_gen.py:295), so ranks must not share a mask stream.  Rank 0 keeps `seed`."""
+    return (int(seed) + int(rank) * 0x9E3779B97F4A7C15) & 0x7FFFFFFFFFFFFFFF
+
+
 class Rng:
     """Device-resident (seed, offset) pair read by every dropout site; graph-capture safe."""
 

@@ -99,6 +99,7 @@ class FusedAdamW(object):
         self.base = base
         self.hp_host = torch.empty(len(base) * 2, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.empty(len(base) * 2)
         self.hp = torch.empty(len(base) * 2, dtype=torch.float32, device=dev)
+        self._sync_step()                      # (a rebuild after replayed steps: the device counter is the truth)
         old = (self.m, self.v) if self._built and self.m.numel() == flat.P.numel() else None
         self.m = torch.zeros_like(flat.P)
         self.v = torch.zeros_like(flat.P)
@@ -111,6 +112,14 @@ class FusedAdamW(object):
         if self._pending is not None:
             sd, self._pending = self._pending, None
             self._apply_state(sd)
+
+    def _sync_step(self):
+        """optimizer.step() count: the DEVICE counter is the source of truth.  Under hipGraph replay `begin_step()` runs once,
+        at capture; the captured `step_dev += 1` then advances on the device with every replay while the host copy stands
+        still -- a checkpoint written from the host copy would restart AdamW's bias correction near t = 1 on warm moments."""
+        if self._built:
+            self.opt_step = int(round(float(self.step_dev.item())))
+        return self.opt_step
 
     def _ensure_built(self):
         flat = self.engine.flat
@@ -181,14 +190,23 @@ class FusedAdamW(object):
             p.grad = None
 
     def state_dict(self):
-        if self._pending is not None and "per_tensor" not in self._pending:
+        if self._pending is not None:          # loaded before the first forward and not applied yet: hand it back unchanged
+            if "per_tensor" in self._pending:
+                return dict(reference_state=self._pending["osd"], sched_step=self.sched_step)
             return dict(self._pending)
-        return dict(m=self.m, v=self.v, opt_step=self.opt_step, sched_step=self.sched_step) if self._built else {}
+        if not self._built:
+            return {}
+        return dict(m=self.m, v=self.v, opt_step=self._sync_step(), sched_step=self.sched_step)
 
     def load_state_dict(self, sd):
         """Usable BEFORE the first forward, as train_gen.py:254-276 does it (checkpoint first, then training): the state is
         kept and applied as soon as the flat buffers exist.  Restores the device step counter too -- AdamW's bias correction
         sqrt(1-b2^t)/(1-b1^t) must continue at t = opt_step, not restart at 1 on warm moments."""
+        if "reference_state" in sd:   # what state_dict() returns for a reference-format state that was never applied
+            self.sched_step = int(sd.get("sched_step", self.sched_step))
+            return self.import_reference_state(sd["reference_state"])
+        if not sd:
+            return
         self.opt_step, self.sched_step = int(sd["opt_step"]), int(sd["sched_step"])
         self._pending = sd
         self._ensure_built()         # applies it now when the engine is ready; otherwise begin_step() will
@@ -207,6 +225,7 @@ class FusedAdamW(object):
         off_of = {id(p): off for p, off in flat.items}
         names = self._names()
         lr_t, lr_i = self.current_lrs()
+        self._sync_step()
         state, groups = {}, []
         for i, (name, p) in enumerate(reference_param_index(self.model)):
             key = names.get(id(p), name) if p is not None else name.split(".", 1)[1]
@@ -234,7 +253,7 @@ class FusedAdamW(object):
                 raise RuntimeError("optimizer state %d (%s): shape %s vs parameter %s" % (i, name, tuple(e["exp_avg"].shape), tuple(p.shape)))
             pend.append((p, e["exp_avg"], e["exp_avg_sq"]))
         self.opt_step = step
-        self._pending = dict(per_tensor=pend, opt_step=step, sched_step=self.sched_step)
+        self._pending = dict(per_tensor=pend, opt_step=step, sched_step=self.sched_step, osd=osd)
         if self._ensure_built() and self._pending is not None:
             sd, self._pending = self._pending, None
             self._apply_state(sd)

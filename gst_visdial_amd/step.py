@@ -86,8 +86,9 @@ class PinnedStager(object):
         self.dev = [dict() for _ in range(depth)]
         self.copy_stream = torch.cuda.Stream(device=self.device) if mode == "pinned_async" else None
         self.copied = [None] * depth          # pinned_async: this slot's H2D has finished
-        self.consumed = [None] * depth        # pinned_async: the compute that read this slot's device buffers has been enqueued
-        self.last_slot = None
+        self.consumed = [None] * depth        # pinned_async: event behind the compute that read this slot's device buffers
+        self.last_slot = None                 # slot handed out by the latest upload(); its consumer is enqueued AFTER that call
+        self._last_marked = True
         self.i = 0
         self.bytes_staged = 0
 
@@ -97,8 +98,23 @@ class PinnedStager(object):
             b = table[slot][k] = torch.empty(v.shape, dtype=v.dtype, **kw)
         return b
 
+    def _mark_consumed(self):
+        """The step that reads the device buffers of the slot handed out by the latest `upload()` is enqueued between that
+        call and the NEXT call into the stager (fill or upload), on the stream that is current then.  So every entry point
+        first records "everything enqueued so far" as that slot's consumed-event; a later `fill()` that reuses the slot makes
+        the copy stream wait on it.  (Round 2 recorded the event only inside the next upload() of a DIFFERENT slot: with the
+        fill-before-upload order of `prefetch()` the H2D of batch k waited on nothing relevant and could overwrite the rows
+        step k-2 -- forward and, in eager mode, backward -- was still reading; a host that runs ahead of the device, as the
+        reference loop with its one sync per 10 iterations does, exposes it.)  Call the stager from the consuming stream."""
+        if self.mode == "pinned_async" and self.last_slot is not None and not self._last_marked:
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(self.device))
+            self.consumed[self.last_slot] = done
+            self._last_marked = True
+
     def fill(self, rows):
         """Host half (+ in mode pinned_async: the H2D is issued on the copy stream right away)."""
+        self._mark_consumed()
         slot = self.i % self.depth
         self.i += 1
         if self.copied[slot] is not None:
@@ -125,16 +141,13 @@ class PinnedStager(object):
 
     def upload(self, filled):
         """Device half: returns the slot's device tensors, ordered on the current stream."""
+        self._mark_consumed()
         slot, keys, nones, ev = filled
         out = {k: None for k in nones}
         if self.mode == "pinned_async":
             cur = torch.cuda.current_stream(self.device)
             cur.wait_event(ev)
-            if self.last_slot is not None and self.last_slot != slot:
-                done = torch.cuda.Event()
-                done.record(cur)                  # everything enqueued so far, incl. the step that read the previous slot
-                self.consumed[self.last_slot] = done
-            self.last_slot = slot
+            self.last_slot, self._last_marked = slot, False
             out.update({k: self.dev[slot][k] for k in keys})
             return out
         for k in keys:

@@ -267,11 +267,14 @@ int32_t gstvd_gemm_group_caps(void);
 int gstvd_gemm_kernel_name(const gstvd_gemm_t* g, int32_t splits, char* buf, int32_t buf_len);
 int gstvd_gemm_grouped_kernel_name(int32_t dtype_in, int32_t dtype_out, int32_t a_kmajor, int32_t b_kmajor, char* buf, int32_t buf_len);
 
-/* Diagnostic (never on the product path): copies the in-kernel clock stamps that the GSTVD_GEMM_ST=3 build of the 256x256 GEMM
- * tile leaves behind -- per workgroup {shader-clock ticks, 100 MHz wall ticks, K steps, 0} around its K loop -- to host memory.
- * Evidence for DESIGN.md's "what clock does an MFMA-dense loop hold" (MI355X_MICROARCH.md, DVFS give-back item 6); replaces
- * nothing in the reference. */
+#ifdef GSTVD_DIAG
+/* DIAGNOSTIC BUILD ONLY (lib/libgstvd_hip_diag.so, `make -C gst_visdial_amd/csrc diag`; the product library neither exports this
+ * symbol nor contains the timing ablations it serves): copies the in-kernel clock stamps that the GSTVD_GEMM_ST=3 variant of the
+ * 256x256 GEMM tile leaves behind -- per workgroup {shader-clock ticks, 100 MHz wall ticks, K steps, 0} around its K loop -- to
+ * host memory.  Evidence for DESIGN.md's "what clock does an MFMA-dense loop hold" (MI355X_MICROARCH.md, DVFS give-back item 6);
+ * replaces nothing in the reference. */
 int gstvd_debug_gemm_clock(uint64_t* out_host, int32_t n_words);
+#endif
 
 #ifdef __cplusplus
 }

@@ -59,8 +59,45 @@ def _lin(sd, name, x):
     return F.linear(x, sd[name + ".weight"], sd[name + ".bias"])
 
 
-def _drop(x, p, train):
-    return F.dropout(x, p, training=True) if (train and p > 0) else x
+class DropMasks(object):
+    """Injected dropout masks (test hook).  `train` arguments throughout this file are either a bool (True: `F.dropout` on the
+    host RNG, what the reference's nn.Dropout modules do) or one of these: a table  site label -> keep mask  (bool / 0-1
+    tensor of the dropped tensor's shape).  A site then computes  x * keep / (1 - p)  -- nn.Dropout's arithmetic with the
+    Bernoulli draw replaced by the given mask and the scale taken from THIS file's own `p` for the site (the reference's
+    config value), so a product that applies the right mask with the wrong probability / scale at a site does not match.
+
+    Site labels (every nn.Dropout the enc_dec_a train step executes; reference lines in the functions that use them):
+      emb.enc / emb.dec            BertEmbeddingsDialog.dropout, encoder / decoder call          vilbert_dialog.py:352
+      vemb                         BertImageEmbeddings.dropout                                   vilbert_dialog.py:1427
+      t<i>.attn .ln1 .ln2          BertLayer i: attention probs, attention output, FFN output    :401,419,461
+      v<i>.attn .ln1 .ln2          BertImageLayer i: the same three                              :528,546,588
+      c<i>.attn1 .attn2            BertBiAttention: dropout1 (probs over vision keys), dropout2  :707,728
+      c<i>.ln1 .ln2 .vln .tln      BertBiOutput.dropout1 / dropout2, v_output / t_output         :735-742,588,461
+      vlf.v / vlf.l                VLFusion.dropout on the vision / text rows of the concat      visual_dialog_model.py:133
+      d<i>.attn .xattn .ln1 .ln2 .ln3   decoder layer i (transformers 4.16.2 BertLayer with cross-attention)
+    `used` records the labels a forward pass asked for, `p_used` the probability the oracle applied there."""
+
+    def __init__(self, table):
+        self.table, self.used, self.p_used = table, [], {}
+
+    def keep(self, label, shape, p):
+        if label not in self.table:
+            raise KeyError("no injected dropout mask for site %r" % (label,))
+        if label in self.p_used:
+            raise KeyError("dropout site %r asked for twice" % (label,))
+        self.used.append(label)
+        self.p_used[label] = p
+        m = self.table[label]
+        return (m != 0).reshape(shape).to(torch.float32)
+
+
+def _drop(x, p, train, label=None):
+    """nn.Dropout(p) in training mode (every call site cites the reference module it stands for)."""
+    if not train or p <= 0:
+        return x
+    if isinstance(train, DropMasks):
+        return x * (train.keep(label, x.shape, p) * (1.0 / (1.0 - p)))
+    return F.dropout(x, p, training=True)
 
 
 def _heads(x, nh):
@@ -73,21 +110,21 @@ def _merge(x):
     return x.permute(0, 2, 1, 3).reshape(B, L, nh * d)
 
 
-def attention_core(q, k, v, add_mask, nh, p_attn, train):
+def attention_core(q, k, v, add_mask, nh, p_attn, train, label=None):
     """softmax(q k^T / sqrt(d) + mask) v -- models/vilbert_dialog.py:389-405
     (scale applied to the scores *before* the additive mask)."""
     qh, kh, vh = _heads(q, nh), _heads(k, nh), _heads(v, nh)
     scores = torch.matmul(qh, kh.transpose(-1, -2)) / math.sqrt(qh.shape[-1])
     scores = scores + add_mask
     probs = torch.softmax(scores, dim=-1)
-    probs = _drop(probs, p_attn, train)
+    probs = _drop(probs, p_attn, train, label)
     return _merge(torch.matmul(probs, vh))
 
 
 # ----------------------------------------------------------------------------
 # encoder
 # ----------------------------------------------------------------------------
-def text_embeddings(sd, prefix, ids, token_type_ids, cfg, train):
+def text_embeddings(sd, prefix, ids, token_type_ids, cfg, train, label="emb.enc"):
     """models/vilbert_dialog.py:324-352 (BertEmbeddingsDialog.forward).
     type embedding = token_type_embeddings[tt] if tt < type_vocab_size else
     token_type_embeddings_extension[tt - type_vocab_size]; `sep_indices`,
@@ -106,7 +143,7 @@ def text_embeddings(sd, prefix, ids, token_type_ids, cfg, train):
     tt = (F.embedding(base_idx, sd[prefix + "token_type_embeddings.weight"]) * base_mask.unsqueeze(-1)
           + F.embedding(ext_idx, sd[prefix + "token_type_embeddings_extension.weight"]) * ext_mask.unsqueeze(-1))
     e = layer_norm_tf(words + pos + tt, sd[prefix + "LayerNorm.weight"], sd[prefix + "LayerNorm.bias"])
-    return _drop(e, cfg["hidden_dropout_prob"], train)
+    return _drop(e, cfg["hidden_dropout_prob"], train, label)
 
 
 def image_embeddings(sd, feats, locs, cfg, train):
@@ -114,21 +151,21 @@ def image_embeddings(sd, feats, locs, cfg, train):
     p = ENC + "v_embeddings."
     e = _lin(sd, p + "image_embeddings", feats) + _lin(sd, p + "image_location_embeddings", locs)
     e = layer_norm_tf(e, sd[p + "LayerNorm.weight"], sd[p + "LayerNorm.bias"])
-    return _drop(e, cfg["hidden_dropout_prob"], train)
+    return _drop(e, cfg["hidden_dropout_prob"], train, "vemb")
 
 
-def _self_block(sd, p, x, add_mask, nh, p_attn, p_hid, train):
+def _self_block(sd, p, x, add_mask, nh, p_attn, p_hid, train, lab=None):
     """attention + output sublayer: vilbert_dialog.py:380-431 / 507-558."""
     ctx = attention_core(_lin(sd, p + "attention.self.query", x), _lin(sd, p + "attention.self.key", x),
-                         _lin(sd, p + "attention.self.value", x), add_mask, nh, p_attn, train)
-    h = _drop(_lin(sd, p + "attention.output.dense", ctx), p_hid, train)
+                         _lin(sd, p + "attention.self.value", x), add_mask, nh, p_attn, train, "%s.attn" % lab)
+    h = _drop(_lin(sd, p + "attention.output.dense", ctx), p_hid, train, "%s.ln1" % lab)
     return layer_norm_tf(h + x, sd[p + "attention.output.LayerNorm.weight"], sd[p + "attention.output.LayerNorm.bias"])
 
 
-def _ffn_block(sd, p_int, p_out, x, p_hid, train):
+def _ffn_block(sd, p_int, p_out, x, p_hid, train, label=None):
     """intermediate + output sublayer: vilbert_dialog.py:445-462 / 572-589."""
     inter = gelu_erf(_lin(sd, p_int + ".dense", x))
-    h = _drop(_lin(sd, p_out + ".dense", inter), p_hid, train)
+    h = _drop(_lin(sd, p_out + ".dense", inter), p_hid, train, label)
     return layer_norm_tf(h + x, sd[p_out + ".LayerNorm.weight"], sd[p_out + ".LayerNorm.bias"])
 
 
@@ -136,16 +173,16 @@ def text_layer(sd, i, x, add_mask, cfg, train):
     """BertLayer, models/vilbert_dialog.py:465-476."""
     p = ENC + "encoder.layer.%d." % i
     a = _self_block(sd, p, x, add_mask, cfg["num_attention_heads"],
-                    cfg["attention_probs_dropout_prob"], cfg["hidden_dropout_prob"], train)
-    return _ffn_block(sd, p + "intermediate", p + "output", a, cfg["hidden_dropout_prob"], train)
+                    cfg["attention_probs_dropout_prob"], cfg["hidden_dropout_prob"], train, "t%d" % i)
+    return _ffn_block(sd, p + "intermediate", p + "output", a, cfg["hidden_dropout_prob"], train, "t%d.ln2" % i)
 
 
 def vision_layer(sd, i, x, add_mask, cfg, train):
     """BertImageLayer, models/vilbert_dialog.py:592-603."""
     p = ENC + "encoder.v_layer.%d." % i
     a = _self_block(sd, p, x, add_mask, cfg["v_num_attention_heads"],
-                    cfg["v_attention_probs_dropout_prob"], cfg["v_hidden_dropout_prob"], train)
-    return _ffn_block(sd, p + "intermediate", p + "output", a, cfg["v_hidden_dropout_prob"], train)
+                    cfg["v_attention_probs_dropout_prob"], cfg["v_hidden_dropout_prob"], train, "v%d" % i)
+    return _ffn_block(sd, p + "intermediate", p + "output", a, cfg["v_hidden_dropout_prob"], train, "v%d.ln2" % i)
 
 
 def connection_layer(sd, i, xv, mask_v, xt, mask_t, cfg, train):
@@ -158,15 +195,15 @@ def connection_layer(sd, i, xv, mask_v, xt, mask_t, cfg, train):
     b = p + "biattention."
     q1, k1, v1 = (_lin(sd, b + n + "1", xv) for n in ("query", "key", "value"))
     q2, k2, v2 = (_lin(sd, b + n + "2", xt) for n in ("query", "key", "value"))
-    ctx1 = attention_core(q2, k1, v1, mask_v, nh, cfg["v_attention_probs_dropout_prob"], train)  # [B,T,Hb]
-    ctx2 = attention_core(q1, k2, v2, mask_t, nh, cfg["attention_probs_dropout_prob"], train)    # [B,R,Hb]
+    ctx1 = attention_core(q2, k1, v1, mask_v, nh, cfg["v_attention_probs_dropout_prob"], train, "c%d.attn1" % i)  # [B,T,Hb]
+    ctx2 = attention_core(q1, k2, v2, mask_t, nh, cfg["attention_probs_dropout_prob"], train, "c%d.attn2" % i)    # [B,R,Hb]
     o = p + "biOutput."
-    hv = _drop(_lin(sd, o + "dense1", ctx2), cfg["v_hidden_dropout_prob"], train)
-    ht = _drop(_lin(sd, o + "dense2", ctx1), cfg["hidden_dropout_prob"], train)
+    hv = _drop(_lin(sd, o + "dense1", ctx2), cfg["v_hidden_dropout_prob"], train, "c%d.ln1" % i)
+    ht = _drop(_lin(sd, o + "dense2", ctx1), cfg["hidden_dropout_prob"], train, "c%d.ln2" % i)
     av = layer_norm_tf(hv + xv, sd[o + "LayerNorm1.weight"], sd[o + "LayerNorm1.bias"])
     at = layer_norm_tf(ht + xt, sd[o + "LayerNorm2.weight"], sd[o + "LayerNorm2.bias"])
-    ov = _ffn_block(sd, p + "v_intermediate", p + "v_output", av, cfg["v_hidden_dropout_prob"], train)
-    ot = _ffn_block(sd, p + "t_intermediate", p + "t_output", at, cfg["hidden_dropout_prob"], train)
+    ov = _ffn_block(sd, p + "v_intermediate", p + "v_output", av, cfg["v_hidden_dropout_prob"], train, "c%d.vln" % i)
+    ot = _ffn_block(sd, p + "t_intermediate", p + "t_output", at, cfg["hidden_dropout_prob"], train, "c%d.tln" % i)
     return ov, ot
 
 
@@ -204,8 +241,11 @@ def encoder_forward(sd, cfg, ids, segments, att_mask, feats, locs, img_mask, tra
 
 def vl_fusion(sd, enc_t, enc_v, att_mask, img_mask, train=False):
     """models/visual_dialog_model.py:131-135: vision first, dropout 0.1."""
-    h = torch.cat((_lin(sd, "vlfusion.fc_v", enc_v), _lin(sd, "vlfusion.fc_l", enc_t)), dim=1)
-    return _drop(h, 0.1, train), torch.cat((img_mask, att_mask), dim=1)
+    hv, hl = _lin(sd, "vlfusion.fc_v", enc_v), _lin(sd, "vlfusion.fc_l", enc_t)
+    mask = torch.cat((img_mask, att_mask), dim=1)
+    if isinstance(train, DropMasks):      # element-wise: dropout of the concat == concat of the halves' dropouts
+        return torch.cat((_drop(hv, 0.1, train, "vlf.v"), _drop(hl, 0.1, train, "vlf.l")), dim=1), mask
+    return _drop(torch.cat((hv, hl), dim=1), 0.1, train), mask
 
 
 # ----------------------------------------------------------------------------
@@ -232,25 +272,28 @@ def _decoder_layer(sd, i, y, self_add, enc_h, cross_add, cfg, train):
     nh, pa, ph = cfg["num_attention_heads"], cfg["attention_probs_dropout_prob"], cfg["hidden_dropout_prob"]
     eps = cfg.get("layer_norm_eps", 1e-12)
     ctx = attention_core(_lin(sd, p + "attention.self.query", y), _lin(sd, p + "attention.self.key", y),
-                         _lin(sd, p + "attention.self.value", y), self_add, nh, pa, train)
-    h = _drop(_lin(sd, p + "attention.output.dense", ctx), ph, train)
+                         _lin(sd, p + "attention.self.value", y), self_add, nh, pa, train, "d%d.attn" % i)
+    h = _drop(_lin(sd, p + "attention.output.dense", ctx), ph, train, "d%d.ln1" % i)
     y1 = layer_norm_tf(h + y, sd[p + "attention.output.LayerNorm.weight"], sd[p + "attention.output.LayerNorm.bias"], eps)
     ctx = attention_core(_lin(sd, p + "crossattention.self.query", y1), _lin(sd, p + "crossattention.self.key", enc_h),
-                         _lin(sd, p + "crossattention.self.value", enc_h), cross_add, nh, pa, train)
-    h = _drop(_lin(sd, p + "crossattention.output.dense", ctx), ph, train)
+                         _lin(sd, p + "crossattention.self.value", enc_h), cross_add, nh, pa, train, "d%d.xattn" % i)
+    h = _drop(_lin(sd, p + "crossattention.output.dense", ctx), ph, train, "d%d.ln2" % i)
     y2 = layer_norm_tf(h + y1, sd[p + "crossattention.output.LayerNorm.weight"],
                        sd[p + "crossattention.output.LayerNorm.bias"], eps)
     inter = gelu_erf(_lin(sd, p + "intermediate.dense", y2))
-    h = _drop(_lin(sd, p + "output.dense", inter), ph, train)
+    h = _drop(_lin(sd, p + "output.dense", inter), ph, train, "d%d.ln3" % i)
     return layer_norm_tf(h + y2, sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"], eps)
 
 
-def decoder_hidden(sd, dec_cfg, dec_ids, dec_att_mask, enc_h, enc_mask, train=False):
+def decoder_hidden(sd, dec_cfg, dec_ids, dec_att_mask, enc_h, enc_mask, train=False, emb_dropout_p=None):
     """BertGenerationEncoder.forward, models/visual_dialog_decoder.py:219-323.
-    The embedding module is the encoder's (train_gen.py:293), called with segments = 0."""
+    The embedding module is the encoder's (train_gen.py:293), called with segments = 0.  `emb_dropout_p`: the probability of
+    that module's nn.Dropout -- the ENCODER config's hidden_dropout_prob (vilbert_dialog.py:321), whoever calls the module
+    (pinned by tests/golden/tiny_train_dropout.npz, where the two configs differ); None = the decoder config's value."""
     B, U = dec_ids.shape
     self_add, cross_add = decoder_masks(dec_att_mask, enc_mask, B, U)
-    y = text_embeddings(sd, DEC + "embeddings.", dec_ids, None, dec_cfg, train)
+    emb_cfg = dec_cfg if emb_dropout_p is None else dict(dec_cfg, hidden_dropout_prob=emb_dropout_p)
+    y = text_embeddings(sd, DEC + "embeddings.", dec_ids, None, emb_cfg, train, "emb.dec")
     for i in range(dec_cfg["num_hidden_layers"]):
         y = _decoder_layer(sd, i, y, self_add, enc_h, cross_add, dec_cfg, train)
     return y
@@ -271,11 +314,11 @@ def shift_labels_(dec_ids, eos=102, pad=0):
 
 
 def decoder_forward(sd, dec_cfg, dec_ids, dec_att_mask, enc_h, enc_mask, labels=None,
-                    loss_reduction=True, train=False, want_loss=True):
+                    loss_reduction=True, train=False, want_loss=True, emb_dropout_p=None):
     """VisualDialogDecoder.forward, models/visual_dialog_decoder.py:33-86 -> (loss, logits, last_hidden)."""
     if labels is None and want_loss:
         labels = shift_labels_(dec_ids, dec_cfg.get("eos_token_id", 102), dec_cfg.get("pad_token_id", 0))
-    y = decoder_hidden(sd, dec_cfg, dec_ids, dec_att_mask, enc_h, enc_mask, train)
+    y = decoder_hidden(sd, dec_cfg, dec_ids, dec_att_mask, enc_h, enc_mask, train, emb_dropout_p)
     logits = lm_logits(sd, y)
     loss = None
     if want_loss:
@@ -294,7 +337,8 @@ def model_forward(sd, enc_cfg, dec_cfg, batch, train=False, loss_reduction=True)
                                    batch["enc_image_spatials"], batch["enc_image_mask"], train)
     enc_h, enc_mask = vl_fusion(sd, enc_t, enc_v, batch["enc_attention_mask"], batch["enc_image_mask"], train)
     loss, logits, y = decoder_forward(sd, dec_cfg, batch["dec_input_ids"], batch.get("dec_attention_mask"),
-                                      enc_h, enc_mask, batch.get("dec_labels"), loss_reduction, train)
+                                      enc_h, enc_mask, batch.get("dec_labels"), loss_reduction, train,
+                                      emb_dropout_p=enc_cfg["hidden_dropout_prob"])
     return dict(loss=loss, logits=logits, enc_hidden_t=enc_t, enc_hidden_v=enc_v,
                 enc_hidden=enc_h, enc_mask=enc_mask, dec_hidden=y)
 
@@ -480,8 +524,9 @@ def live_param_keys(sd):
     return keys
 
 
-def grads(sd, enc_cfg, dec_cfg, batch, wrt_keys, wrt_feats=True):
-    """loss.backward() through the oracle; returns (outputs, {key: grad}, d loss/d image feats)."""
+def grads(sd, enc_cfg, dec_cfg, batch, wrt_keys, wrt_feats=True, train=False):
+    """loss.backward() through the oracle; returns (outputs, {key: grad}, d loss/d image feats).
+    `train`: False (eval), True (host-RNG dropout) or a DropMasks table (injected masks)."""
     sd = {k: v.detach().clone() for k, v in sd.items()}
     # restore aliasing so shared tensors accumulate both contributions
     for k in list(sd):
@@ -493,7 +538,7 @@ def grads(sd, enc_cfg, dec_cfg, batch, wrt_keys, wrt_feats=True):
     batch = dict(batch)
     feats = batch["enc_image_features"].detach().clone().requires_grad_(wrt_feats)
     batch["enc_image_features"] = feats
-    out = model_forward(sd, enc_cfg, dec_cfg, batch, train=False)
+    out = model_forward(sd, enc_cfg, dec_cfg, batch, train=train)
     out["loss"].backward()
     g = {k: sd[k].grad for k in wrt_keys}
     return out, g, feats.grad

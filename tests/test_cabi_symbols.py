@@ -11,6 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols():
     src = open(os.path.join(ROOT, "include", "gstvd_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"#ifdef GSTVD_DIAG.*?#endif", "", src, flags=re.S)      # entry points of the diagnostic build (tools/ only)
     return sorted(set(re.findall(r"\b(gstvd_[a-z0-9_]+)\s*\(", src)))
 
 
@@ -41,3 +42,18 @@ def test_ops_refuse_cpu_tensors():
     a = torch.zeros(8, 8)
     with pytest.raises(_lib.GstvdError):
         ops.gemm(a, a, a, 8, 8, 8)
+
+
+def test_product_library_carries_no_timing_ablations():
+    """an environment variable must not be able to make the product compute wrong results.  The ablation
+    selector and the in-kernel clock probe live in the -DGSTVD_DIAG build (lib/libgstvd_hip_diag.so, `make diag`, tools/ only)."""
+    from gst_visdial_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as ge
+        ge.build()
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for needle in (b"GSTVD_GEMM_ABLATE", b"GSTVD_DIAG_ABLATE", b"gstvd_debug_gemm_clock", b"g_clk256"):
+        assert needle not in blob, needle
+    assert b"GSTVD_GEMM_PC" in blob                                           # (the scan does see getenv strings)
+    assert not hasattr(_lib.load(), "gstvd_debug_gemm_clock")
+    assert "diag" not in os.path.basename(_lib.LIB_PATH)

@@ -79,6 +79,48 @@ def test_full_model_fp32_logits_and_loss_match_oracle(full_fp32):
     assert _rel(feats.grad, ref["dfeats"]) <= 5e-4
 
 
+def test_full_model_seq_len_256_train_mode_matches_oracle_under_engine_masks(full_fp32):
+    """The shape AND mode the bench times (BASELINE configs[1]: seq_len 256 -> four 64-key chunks, positions 128-255, 293
+    cross-attention keys; dropout on), on the 388 M-parameter model, 2 rows, fp32 parity mode: the engine's train-mode step
+    against the oracle run with the masks the engine drew (155 sites; selfcheck.dropout_keep_masks).  Logits 1e-4, loss 1e-5,
+    gradients across the depth of the network 5e-4 of each tensor's max."""
+    import bench
+    from gst_visdial_amd import selfcheck
+    from gst_visdial_amd.config import bert_base_enc_config, bert_base_dec_config
+    model, _, sd, _, keys, _ = full_fp32
+    O = _oracle()
+    V = model.decoder.config.vocab_size
+    batch = bench.synthetic_rows(2, 256, 37, 25, 2048, V, 8765, DEV)
+    assert int(batch["enc_attention_mask"].sum(1).max()) > 200          # positions beyond 128 are really used
+    model.train()
+    try:
+        model.zero_grad(set_to_none=True)
+        feats = batch["enc_image_features"].clone().requires_grad_(True)
+        loss, logits = model(**dict(batch, enc_image_features=feats))
+        loss.backward()
+        torch.cuda.synchronize()
+        eng = model.engine
+        table = selfcheck.dropout_keep_masks(eng)
+        assert len(table) == 155 and len({v["site"] for v in eng.site_log.values()}) == 155
+        masks = O.DropMasks(table)
+        torch.set_num_threads(min(os.cpu_count() or 1, 16))
+        cpu_batch = {k: v.cpu() for k, v in batch.items()}
+        out, g, dfe = O.grads(sd, bert_base_enc_config(), bert_base_dec_config(), cpu_batch, keys, wrt_feats=True, train=masks)
+        assert set(masks.used) == set(eng.site_log)
+        for lab, v in eng.site_log.items():
+            assert abs(v["p"] - masks.p_used[lab]) < 1e-12, lab
+        err = (logits.float().cpu() - out["logits"]).abs().max().item()
+        assert err <= 1e-4, "train-mode fp32 logits at seq_len 256 differ from the oracle by %.3e" % err
+        assert abs(loss.item() - out["loss"].item()) <= 1e-5 * max(1.0, abs(out["loss"].item()))
+        named = dict(model.named_parameters())
+        worst = {k: _rel(named[k].grad, g[k]) for k in keys if k in named}
+        assert len(worst) >= 8 and max(worst.values()) <= 5e-4, worst
+        assert _rel(feats.grad, dfe) <= 5e-4
+    finally:
+        model.eval()
+        model.zero_grad(set_to_none=True)
+
+
 def test_full_model_bf16_close_to_oracle(full_fp32):
     import bench
     model32, batch, sd, cpu_batch, keys, ref = full_fp32

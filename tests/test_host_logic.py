@@ -338,3 +338,21 @@ def test_capture_guard_collects_before_and_disables_gc_during():
             seen.append(gc.isenabled())
         seen.append(gc.isenabled())
     assert seen == [False, False, False] and gc.isenabled()
+
+
+def test_deepcopy_of_a_model_gets_its_own_engine():
+    """the engine holds its model weakly; copy.deepcopy(model) must not leave the copy's engine bound to the
+    original (nor give the copy's encoder / decoder holders a third engine)."""
+    import copy
+    model, enc, dec = _tiny_model()
+    eng = model.engine
+    twin = copy.deepcopy(model)
+    assert twin.engine is not eng and twin.engine.model is twin and eng.model is model
+    assert twin.encoder._standalone_engine is twin.engine and twin.decoder._standalone_engine is twin.engine
+
+
+def test_rank_seed_gives_every_rank_its_own_dropout_stream():
+    from gst_visdial_amd import ops
+    seeds = [ops.rank_seed(1234, r) for r in range(8)]
+    assert seeds[0] == 1234 and len(set(seeds)) == 8 and all(0 <= s < 2 ** 63 for s in seeds)
+    assert len({s & 0xffffffff for s in seeds}) == 8 and len({s >> 32 for s in seeds}) == 8     # both words the kernels hash differ

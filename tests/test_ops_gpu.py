@@ -677,6 +677,18 @@ def test_skinny_decode_gemm(M, N, K, out):
         aref.backward(torch.ones_like(aref))
         check("skinny_gelu", a, aref.detach(), torch.bfloat16)
         check("skinny_gelu_deriv", u, uref.grad, torch.bfloat16)
+    else:
+        # fp32 output + residual add: the addend has the OUTPUT's type (the skinny kernels read it as bf16)
+        r = rnd(M, N, seed=43)
+        y2 = torch.empty(M, N, device=DEV, dtype=out)
+        o.gemm(x, w, y2, M, N, K, bias=b, addend=r)
+        check("skinny_add_f32", y2, ref + r, torch.bfloat16)
+        if K <= 1024 and K % 8 == 0:
+            gamma, beta = 1.0 + rnd(K, seed=44, s=0.1), rnd(K, seed=45, s=0.1)
+            y3 = torch.empty(M, N, device=DEV, dtype=out)
+            o.gemv_ln(x, w, y3, M, N, K, gamma, beta, 1e-12, bias=b, addend=r)
+            xn = torch.nn.functional.layer_norm(x.float(), (K,), gamma, beta, 1e-12).to(torch.bfloat16).float()
+            check("skinny_ln_add_f32", y3, xn @ w.float().t() + b + r, torch.bfloat16)
     from gst_visdial_amd import _lib as L
     d = L.GemmDesc()
     d.A, d.B, d.C, d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.batch = x.data_ptr(), w.data_ptr(), y.data_ptr(), M, N, K, K, K, 3 * N, 1

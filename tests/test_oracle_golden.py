@@ -245,3 +245,49 @@ def test_train_loop_with_restated_adamw_follows_the_reference_run(tiny_cfg, tiny
     worst = max((params[k].data - tr["state5::" + k]).abs().max().item() / max(tr["state5::" + k].abs().max().item(), 1e-6) for k in keys)
     assert worst < 2e-4, worst
     assert torch.equal(tr["state5::vlfusion.fc_v.weight"], tiny_state["vlfusion.fc_v.weight"])       # never trained by the reference
+
+
+# ---- round 3: TRAIN mode (dropout on) under injected masks, oracle/make_golden_r3.py -------------------------------------
+def _dropout_fixture():
+    from conftest import load_npz
+    g = load_npz("tiny_train_dropout.npz")
+    with open(os.path.join(GOLDEN, "tiny_cfg_dropout.json")) as f:
+        cfg = json.load(f)
+    return g, cfg
+
+
+def test_train_mode_under_injected_masks_matches_the_reference(tiny_state, tiny_train):
+    """The reference ran model.train() with every nn.Dropout / functional dropout call replaced by x * mask / (1 - p_site)
+    (p_site = what the reference's own call site passed).  The oracle, given the same masks by site label, must reproduce
+    loss / logits / fused encoder states / the 29 golden-key gradients -- with ITS OWN probability per site, read from the
+    config the way the reference's modules were constructed.  The config gives every dropout family a different value, so
+    this pins which probability belongs to which site (incl. the decoder's embedding dropout = the ENCODER's value)."""
+    g, cfg = _dropout_fixture()
+    masks = O.DropMasks({k[6:]: v for k, v in g.items() if k.startswith("mask::")})
+    keys = [k[6:] for k in g if k.startswith("grad::")]
+    out, gr, dfeat = O.grads(tiny_state, cfg["enc"], cfg["dec"], batch_from_golden(tiny_train), keys, train=masks)
+    assert masks.used == cfg["site_order"]                      # every site of the reference's step, in its order, once
+    for lab in masks.used:
+        assert abs(masks.p_used[lab] - g["p::" + lab].item()) < 1e-12, (lab, masks.p_used[lab], g["p::" + lab].item())
+    close(out["logits"], g["logits"])
+    close(out["enc_hidden"], g["enc_hidden"])
+    close(out["loss"], g["loss"], 1e-5)
+    for k in keys:
+        ref = g["grad::" + k]
+        scale = max(ref.abs().max().item(), 1e-3)
+        close(gr[k] / scale, ref / scale, 5e-5)
+    close(dfeat, g["d_feats"], 1e-6)
+
+
+def test_injected_masks_are_not_a_no_op(tiny_state, tiny_train):
+    """Sanity of the hook itself: other masks -> other outputs; a missing site raises."""
+    g, cfg = _dropout_fixture()
+    table = {k[6:]: v for k, v in g.items() if k.startswith("mask::")}
+    flipped = dict(table)
+    flipped["d1.ln3"] = 1 - table["d1.ln3"]
+    out = O.model_forward(tiny_state, cfg["enc"], cfg["dec"], batch_from_golden(tiny_train), train=O.DropMasks(flipped))
+    assert (out["logits"] - g["logits"]).abs().max().item() > 1e-3
+    del flipped["c0.attn2"]
+    import pytest
+    with pytest.raises(KeyError):
+        O.model_forward(tiny_state, cfg["enc"], cfg["dec"], batch_from_golden(tiny_train), train=O.DropMasks(flipped))

@@ -1,0 +1,324 @@
+"""Round 3: parity of the mode the bench times -- TRAIN mode, dropout ON -- against the CPU oracle.
+
+The oracle's train-mode arithmetic is pinned to the reference by tests/test_oracle_golden.py (the reference run under
+injected masks, oracle/make_golden_r3.py).  Here the engine runs a train-mode step with its own counter-based masks; the
+masks it drew are regenerated per site (selfcheck.dropout_keep_masks -> gstvd_dropout_mask) and handed to the oracle, which
+applies them with ITS OWN probability per site.  A wrong probability at a site, a site number used twice, a missing
+1/(1-p) in one backward, a site the engine skips -- each breaks the comparison.  The tiny config gives every dropout family
+its own probability (tests/golden/tiny_cfg_dropout.json).
+Tolerances: fp32 mode logits <= 1e-4 (north_star), loss <= 1e-5, gradients <= 2e-4 of each tensor's max; bf16 mode loss
+<= 3e-2, logits <= 0.1, per-tensor gradient error <= 3e-2 of the tensor's norm (where the fp32 gradient is not negligible)."""
+import json
+import os
+import sys
+
+import pytest
+import torch
+
+from conftest import GOLDEN, load_npz
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def sc():
+    from gst_visdial_amd import selfcheck
+    return selfcheck
+
+
+def _oracle():
+    from oracle import vd_oracle as O
+    return O
+
+
+def _cpu_batch(g):
+    return {k[4:]: v.clone() for k, v in g.items() if k.startswith("in::")}
+
+
+def _oracle_under_engine_masks(model, cfg, g, keys=None):
+    """Oracle loss / logits / gradients for the step the engine just ran: same weights, same batch, the engine's own masks."""
+    O = _oracle()
+    s = sc()
+    eng = model.engine
+    table = s.dropout_keep_masks(eng)
+    masks = O.DropMasks(table)
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    if keys is None:
+        keys = [k for k in O.live_param_keys(sd)]
+    out, gr, dfe = O.grads(sd, cfg["enc"], cfg["dec"], _cpu_batch(g), keys, wrt_feats=True, train=masks)
+    # the site bookkeeping itself: every engine site was consumed exactly once by the oracle, no site number twice,
+    # and the engine's probability at each site is the oracle's (i.e. the reference's)
+    log = eng.site_log
+    assert set(masks.used) == set(log), (set(log) ^ set(masks.used))
+    assert len({v["site"] for v in log.values()}) == len(log)
+    for lab, v in log.items():
+        assert abs(v["p"] - masks.p_used[lab]) < 1e-12, (lab, v["p"], masks.p_used[lab])
+    return out, gr, dfe, table
+
+
+def _grad_of(model, key):
+    named = dict(model.named_parameters())
+    p = named.get(key)
+    return None if p is None else p.grad
+
+
+def _check_grads(model, gr, rel_max=None, rel_norm=None):
+    worst = ("", 0.0)
+    n = 0
+    for k, ref in gr.items():
+        got = _grad_of(model, k)
+        if got is None:                                  # aliased names (decoder.* embeddings) appear once
+            continue
+        got = got.float().cpu()
+        n += 1
+        if rel_max is not None:
+            e = (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-3)
+            if e > worst[1]:
+                worst = (k, e)
+            assert e < rel_max, (k, e)
+        else:
+            rn = ref.norm().item()
+            if rn < 1e-4:                                # e.g. key.bias: softmax is shift invariant, the true gradient is 0
+                assert got.norm().item() < 1e-2, (k, got.norm().item())
+                continue
+            e = (got - ref).norm().item() / rn
+            if e > worst[1]:
+                worst = (k, e)
+            assert e < rel_norm, (k, e)
+    assert n >= 150, n
+    return worst
+
+
+@pytest.fixture(scope="module")
+def drop_cfg():
+    with open(os.path.join(GOLDEN, "tiny_cfg_dropout.json")) as f:
+        return json.load(f)
+
+
+def test_train_mode_fp32_matches_oracle_under_the_engines_own_masks(drop_cfg):
+    s = sc()
+    g = load_npz("tiny_train.npz")
+    model, params, cfg = s.build_tiny_model("fp32", DEV, seed=11, cfg_file="tiny_cfg_dropout.json")
+    model.train()
+    feats = g["in::enc_image_features"].clone().to(DEV).requires_grad_(True)
+    kw = s.golden_batch(g, DEV)
+    kw["enc_image_features"] = feats
+    for step in range(2):                                # second step: the offset has advanced, other masks, same bars
+        model.zero_grad(set_to_none=True)
+        feats.grad = None
+        loss, logits = model(**kw)
+        loss.backward()
+        torch.cuda.synchronize()
+        out, gr, dfe, table = _oracle_under_engine_masks(model, drop_cfg, g)
+        assert len(table) == 45                          # every dropout of the reference's train step (make_golden_r3: 45 sites)
+        assert (logits.float().cpu() - out["logits"]).abs().max().item() < 1e-4
+        assert abs(loss.item() - out["loss"].item()) < 1e-5
+        _check_grads(model, gr, rel_max=2e-4)
+        assert (feats.grad.cpu() - dfe).abs().max().item() < 1e-5 + 2e-4 * dfe.abs().max().item()
+        if step == 0:
+            first = {k: v.clone() for k, v in table.items()}
+        else:
+            assert any(not torch.equal(first[k], table[k]) for k in table)
+    # drop rates are what the config says (a mask drawn with another family's probability would still "match itself")
+    for lab, m in table.items():
+        p = model.engine.site_log[lab]["p"]
+        rate = 1.0 - m.float().mean().item()
+        n = m.numel()
+        assert abs(rate - p) < 5.0 * (p * (1 - p) / n) ** 0.5 + 1e-3, (lab, p, rate)
+
+
+def test_train_mode_bf16_close_to_oracle_under_the_engines_own_masks(drop_cfg):
+    s = sc()
+    g = load_npz("tiny_train.npz")
+    model, params, cfg = s.build_tiny_model("bf16", DEV, seed=5, cfg_file="tiny_cfg_dropout.json")
+    model.train()
+    loss, logits = model(**s.golden_batch(g, DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    out, gr, dfe, table = _oracle_under_engine_masks(model, drop_cfg, g)
+    assert abs(loss.item() - out["loss"].item()) < 3e-2
+    assert (logits.float().cpu() - out["logits"]).abs().max().item() < 0.1
+    worst = _check_grads(model, gr, rel_norm=3e-2)
+    print("bf16 train-mode worst per-tensor gradient error (norm-relative):", worst)
+
+
+def test_eval_mode_bf16_gradients_per_tensor_relative_error():
+    """Replaces the cosine >= 0.98 bar (which admits a 20 % gradient error): every live tensor's bf16 gradient within 3e-2 of
+    its fp32 oracle gradient, in the tensor's norm."""
+    s = sc()
+    O = _oracle()
+    g = load_npz("tiny_train.npz")
+    model, params, cfg = s.build_tiny_model("bf16", DEV)
+    model.eval()
+    loss, logits = model(**s.golden_batch(g, DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    _, gr, _ = O.grads(sd, cfg["enc"], cfg["dec"], _cpu_batch(g), O.live_param_keys(sd))
+    worst = _check_grads(model, gr, rel_norm=3e-2)
+    print("bf16 eval-mode worst per-tensor gradient error (norm-relative):", worst)
+
+
+@pytest.mark.isolated
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_bench_path_graph_replay_with_pipeline_matches_oracle_in_train_mode(drop_cfg, precision):
+    """The path bench.py times: GraphedStep replay of forward + backward + BackwardPipeline (grouped weight gradients, fused
+    AdamW on the auxiliary stream), dropout on, device-resident dropout offset advancing inside the graph.  After a replay
+    the flat gradient buffer holds that step's gradients and the rng state is the one the replay used: regenerate its masks,
+    run the oracle on the weights the replay STARTED from, compare loss and all gradients."""
+    s = sc()
+    from gst_visdial_amd.graph import GraphedStep
+    from gst_visdial_amd.optim import FusedAdamW
+    from gst_visdial_amd.pipeline import BackwardPipeline
+    g = load_npz("tiny_train.npz")
+    model, params, cfg = s.build_tiny_model(precision, DEV, seed=21, cfg_file="tiny_cfg_dropout.json")
+    model.train()
+    kw = s.golden_batch(g, DEV)
+    opt = FusedAdamW(model, lr=1e-3)
+    BackwardPipeline(model.engine, optimizer=opt, chunk_elems=60000)
+
+    def device_step():
+        loss, _ = model(**kw)
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        return loss
+
+    replay = GraphedStep(device_step, warmup=2)
+    eng = model.engine
+    for it in range(2):
+        torch.cuda.synchronize()
+        before = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+        loss = replay()
+        torch.cuda.synchronize()
+        O = _oracle()
+        masks = O.DropMasks(s.dropout_keep_masks(eng))
+        keys = O.live_param_keys(before)
+        out, gr, _ = O.grads(before, drop_cfg["enc"], drop_cfg["dec"], _cpu_batch(g), keys, wrt_feats=False, train=masks)
+        assert set(masks.used) == set(eng.site_log)
+        tol_loss = 1e-5 if precision == "fp32" else 3e-2
+        assert abs(loss.item() - out["loss"].item()) < tol_loss, (it, loss.item(), out["loss"].item())
+        flat = eng.flat
+        off_of = {id(p): (off, p) for p, off in flat.items}
+        named = dict(model.named_parameters())
+        n = 0
+        for k, ref in gr.items():
+            p = named.get(k)
+            if p is None or id(p) not in off_of:
+                continue
+            off = off_of[id(p)][0]
+            got = flat.G[off:off + p.numel()].view(p.shape).float().cpu()
+            n += 1
+            if precision == "fp32":
+                e = (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-3)
+                assert e < 2e-4, (it, k, e)
+            else:
+                rn = ref.norm().item()
+                if rn < 1e-4:
+                    continue
+                e = (got - ref).norm().item() / rn
+                assert e < 3e-2, (it, k, e)
+        assert n >= 140, n
+        # and the update really happened from those gradients: parameters moved
+        after = model.state_dict()
+        k0 = "encoder.bert_pretrained.bert.encoder.layer.0.attention.self.query.weight"
+        assert (after[k0].float().cpu() - before[k0]).abs().max().item() > 0
+
+
+# ---- PinnedStager slot reuse while the consuming step is still running ---------------------------------
+def test_stager_never_overwrites_a_slot_its_consumer_is_still_reading():
+    """No host synchronisation inside the loop and a long spin kernel in front of every consumer, so the host (fills, H2D
+    issue) runs far ahead of the device -- the situation of the reference loop (one sync per 10 iterations).  Each "step"
+    reads its rows only AFTER the spin; with depth 2 batch k+2 reuses batch k's slot.  Every step must still see its own rows,
+    in the fill-before-upload order of step.prefetch() and in bench.py's upload-step-fill order."""
+    from gst_visdial_amd import step
+    n, rows_n = 8, 1 << 16
+    host = [dict(x=torch.full((rows_n,), float(k + 1)), y=torch.arange(rows_n, dtype=torch.int64) + 1000 * k) for k in range(n)]
+    spin = 20_000_000                                    # ~10 ms per consumer
+
+    def consume(rows, out, k):
+        torch.cuda._sleep(spin)
+        out[k, 0] = rows["x"].sum()
+        out[k, 1] = rows["y"].sum().float()
+        out[k, 2] = rows["x"].min() - rows["x"].max()
+
+    want = torch.tensor([[float(h["x"].sum()), float(h["y"].sum()), 0.0] for h in host])
+    for order in ("prefetch", "bench"):
+        st = step.PinnedStager(DEV, depth=2)
+        out = torch.zeros(n, 3, device=DEV)
+        if order == "prefetch":
+            pending = None
+            for k in range(n):
+                h = st.fill(host[k])
+                if pending is not None:
+                    consume(st.upload(pending[0]), out, pending[1])
+                pending = (h, k)
+            consume(st.upload(pending[0]), out, pending[1])
+        else:
+            pending = st.fill(host[0])
+            for k in range(n):
+                rows = st.upload(pending)
+                consume(rows, out, k)
+                if k + 1 < n:
+                    pending = st.fill(host[k + 1])
+        torch.cuda.synchronize()
+        assert torch.equal(out.cpu(), want), (order, out.cpu(), want)
+
+
+# ---- optimizer step count in checkpoints written after hipGraph-replayed training --------------------
+@pytest.mark.isolated
+def test_checkpoint_after_graph_replays_records_the_device_step_count_and_resumes_identically(tmp_path):
+    """begin_step() runs once (at capture) under GraphedStep; the AdamW step counter advances on the device.  state_dict() /
+    export_reference_state() must report the device count, and a model resumed from such a checkpoint must continue exactly
+    like the uninterrupted run (bias correction at t = steps so far, not t ~ 1 on warm moments)."""
+    s = sc()
+    from gst_visdial_amd.checkpoint import load_checkpoint, save_checkpoint
+    from gst_visdial_amd.graph import GraphedStep
+    from gst_visdial_amd.optim import FusedAdamW
+    g = load_npz("tiny_train.npz")
+
+    def make():
+        model, params, cfg = s.build_tiny_model("fp32", DEV)
+        model.eval()                                       # dropout off: both runs are deterministic functions of the weights
+        opt = FusedAdamW(model, lr=5e-3)
+        kw = s.golden_batch(g, DEV)
+
+        def device_step():
+            loss, _ = model(**kw)
+            loss.backward()
+            opt.step()
+            opt.zero_grad()
+            return loss
+        return model, opt, device_step
+
+    model, opt, device_step = make()
+    replay = GraphedStep(device_step, warmup=2)            # 2 eager + 1 captured (capture executes nothing) = 2 steps done
+    torch.cuda.synchronize()
+    done = int(opt.step_dev.item())
+    for _ in range(4):
+        replay()
+    torch.cuda.synchronize()
+    assert int(opt.step_dev.item()) == done + 4
+    sd = opt.state_dict()
+    assert sd["opt_step"] == done + 4                      # (round 2: stuck at the host's count)
+    ref = opt.export_reference_state()
+    assert all(int(v["step"]) == done + 4 for v in ref["state"].values()) and len(ref["state"]) > 100
+    for fmt in (False, True):
+        path = str(tmp_path / ("ck_%d.pt" % fmt))
+        save_checkpoint(path, model, opt, iter_id=done + 4, reference_format=fmt)
+        m2, o2, step2 = make()
+        load_checkpoint(path, m2, o2)
+        for _ in range(2):
+            step2()
+        torch.cuda.synchronize()
+        if not fmt:                                        # continue the original once, compare both resumes against it
+            replay(); replay()
+            torch.cuda.synchronize()
+            want = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+        got = m2.state_dict()
+        worst = max((got[k].float().cpu() - want[k]).abs().max().item() for k in want)
+        assert worst < 2e-6, (fmt, worst)
+        assert int(o2.step_dev.item()) == done + 6

@@ -20,8 +20,8 @@ bash tools/pmc_mfma.sh > $out/pmc_mfma.log 2>&1; cp gpurun_out/pmc_mfma/summary.
 # 7. timeline of a replayed step
 bash tools/timeline.sh > $out/timeline.txt 2>&1
 # 8. GEMM K-loop study: K slope + ablations + in-kernel clock (diagnostic builds, env-selected)
-( for ab in 0 1 7 2; do GSTVD_GEMM_ABLATE=$ab python3 tools/clock_probe.py 3072; done
-  for ab in 0 1 2 6; do GSTVD_GEMM256_NIU=4 GSTVD_GEMM_ABLATE=$ab python3 tools/kslope.py nt 4096 4096 | sed "s/^/ABLATE=$ab /"; done
+( for ab in 0 1 7 2; do GSTVD_DIAG_ABLATE=$ab python3 tools/clock_probe.py 3072; done
+  for ab in 0 1 2 6; do GSTVD_GEMM256_NIU=4 GSTVD_DIAG_ABLATE=$ab python3 tools/kslope.py nt 4096 4096 | sed "s/^/ABLATE=$ab /"; done
   for st in 0 4; do GSTVD_GEMM256_NIU=4 GSTVD_GEMM_ST=$st python3 tools/kslope.py nt 4096 4096 | sed "s/^/ST=$st /"; done
   python3 tools/kslope.py nt 4096 768 64; python3 tools/kslope.py nn 4096 768 64
   python3 tools/gemm_bench.py all; python3 tools/write_floor.py ) > $out/gemm_study.txt 2>/dev/null

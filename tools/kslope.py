@@ -1,8 +1,13 @@
 #!/usr/bin/env python3
 """Per-K-step time and fixed cost of a GEMM tile class: times LAYOUT MxNxK at several K and fits t = fixed + slope * steps.
-usage: kslope.py LAYOUT M N [kstep=32]   (tuning / ablation env vars GSTVD_GEMM_* apply)"""
+usage: kslope.py LAYOUT M N [kstep=32]   (tuning env vars GSTVD_GEMM_* apply; with GSTVD_DIAG_ABLATE set the DIAGNOSTIC library
+is built and loaded instead of the product one -- tools/diag_lib.py)"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+if os.environ.get("GSTVD_DIAG_ABLATE"):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import diag_lib
+    diag_lib.use()
 import torch
 from gst_visdial_amd import ops
 lay, M, N = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
