@@ -157,10 +157,11 @@ def main():
                     help="dtype of the gradient all-reduce payload (auto: bf16 for N>1 -- halves xGMI traffic; fp32 master grads kept)")
     ap.add_argument("--breakdown-json", default=None, help="write the per-kernel breakdown here")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
-                    help="replay the whole train step as one hipGraph (auto: on for 1 GPU, off for N>1)")
+                    help="replay the whole train step as one hipGraph (auto = on at every N: at N>1 the RCCL all-reduces are captured "
+                         "with the step and a failed capture is a hard error; off: eager issue, host bound)")
     ap.add_argument("--no-pipeline", action="store_true", help="diagnostic: no backward pipeline (wgrad/AdamW after backward, same stream)")
     ap.add_argument("--chunk-melems", type=int, default=0,
-                    help="backward-pipeline slice size in Mi elements (0 = auto: 192 at N=1, 40 at N>1)")
+                    help="backward-pipeline slice size in Mi elements (0 = auto: 192 at N=1; graded 128,96,96,32,16 at N>1)")
     ap.add_argument("--chunk-list", default="", help="graded backward-pipeline slice sizes in Mi elements, comma separated (overrides --chunk-melems)")
     ap.add_argument("--no-streams", action="store_true", help="run the vision stream on the main HIP stream")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 parity-mode timing beside the bf16 headline")
@@ -217,7 +218,7 @@ def main():
     opt = FusedAdamW(model, lr=2e-5, warmup_steps=1500, t_total=100000)
     # gradients are finalised slice by slice on a third stream during backward: grouped wgrad GEMMs -> column
     # reductions -> (N>1) RCCL all-reduce of the slice -> fused AdamW on the slice
-    compress = {"auto": "bf16" if world > 1 else None, "none": None, "bf16": "bf16"}[args.grad_compress]
+    compress = {"auto": "bf16" if (world > 1 or force_dist) else None, "none": None, "bf16": "bf16"}[args.grad_compress]
     # Slice size: at N>1 many slices let each all-reduce overlap the rest of backward and keep the exposed tail (last
     # slice's wgrad + all-reduce + AdamW) short; at N=1 there is nothing to hide and two large slices are faster (measured
     # 15.4 ms at 40 Mi, 14.8 ms at 192 Mi: the grouped wgrad launches are larger, AdamW streams less often through L2)
@@ -321,6 +322,19 @@ def main():
         dt = float(tmax.item())
     ms_step = dt * 1000.0 / args.steps
     rows_s = B * world * args.steps / dt
+    rccl_info = None
+    if world > 1 or force_dist:
+        import torch.distributed as dist
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:          # noqa: BLE001
+            ver = None
+        seen = torch.ones(1, device=device)
+        dist.all_reduce(seen)                                  # = number of ranks the communicator really spans
+        rccl_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_seen_by_allreduce": int(seen.item()),
+                     "rccl_version": ver, "payload_dtype": compress or "fp32", "payload_summed_in": compress or "fp32",
+                     "slices_per_step": len(pipe.slices) if pipe is not None else None,
+                     "one_gpu_validation_mode": bool(one_gpu)}
 
     # host issue time of one step (no sync inside): if this approaches ms_per_step the run is launch bound
     torch.cuda.synchronize()
@@ -492,7 +506,13 @@ def main():
                "roofline": roofline, "cpu_baseline": cpu}
         if breakdown is not None:
             out["kernel_breakdown_ms"] = {k: v["ms"] for k, v in list(breakdown.items())[:12]}
-        out["config"]["grad_allreduce_dtype"] = (compress or "fp32") if world > 1 else None
+        collective = world > 1 or force_dist
+        out["config"]["grad_allreduce_dtype"] = (compress or "fp32") if collective else None
+        # what the communicator really is (N>1 only runs on the driver's node: this is the evidence that it was RCCL, over how
+        # many ranks, with which payload); summing bf16 payloads IN bf16 deviates from the reference's fp32 reduce-add by
+        # <= 4e-3 of a tensor's norm at 8 ranks (tests/test_dp_gloo.py::test_eight_rank_graded_slices_bf16_payload_error_bound)
+        out["config"]["rccl"] = rccl_info if collective else None
+        out["config"]["dropout_seed_per_rank"] = True
         from gst_visdial_amd import graph as _g
         out["config"]["capture_quiesce"] = _g.LAST_QUIESCE[0] if use_graph else None
         out["config"]["fp32_parity_mode_ms_per_step"] = fp32_ms

@@ -28,15 +28,15 @@ def _batch(sc, g, rows, dev):
     return {k: (v[idx].clone() if torch.is_tensor(v) else v) for k, v in kw.items()}
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, train=False):
     try:
-        _worker_body(rank, world, port, q)
+        _worker_body(rank, world, port, q, train)
     except BaseException as ex:          # noqa: BLE001 -- report instead of dying silently
         import traceback
         q.put((rank, "ERROR: " + "".join(traceback.format_exception(type(ex), ex, ex.__traceback__))[-1500:]))
 
 
-def _worker_body(rank, world, port, q):
+def _worker_body(rank, world, port, q, train):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     import torch.distributed as dist
@@ -46,7 +46,7 @@ def _worker_body(rank, world, port, q):
     from gst_visdial_amd.pipeline import BackwardPipeline
     dev = "cuda:0"
     model, params, cfg = sc.build_tiny_model("fp32", dev, seed=4)
-    model.eval()
+    model.train(train)
     g = sc.load_npz("tiny_train.npz")
     kw = _batch(sc, g, ROWS[rank], dev)
     opt = FusedAdamW(model, lr=2e-3)
@@ -59,29 +59,43 @@ def _worker_body(rank, world, port, q):
         opt.zero_grad()
         losses.append(loss.item())
     torch.cuda.synchronize()
+    mask = None
+    if train:           # the keep mask this rank's LAST step drew at one site (ranks must not share a mask stream)
+        mask = sc.dropout_keep_masks(model.engine)["t0.ln1"].numpy().copy()
     # numpy, not torch: a tensor would travel as a shared-memory handle that dies with this process
-    q.put((rank, losses, model.engine.flat.P.detach().cpu().numpy(), len(pipe.slices), opt.grad_scale))
+    q.put((rank, losses, model.engine.flat.P.detach().cpu().numpy(), len(pipe.slices), opt.grad_scale, mask,
+           int(model.engine.rng.state[0].item())))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_pipeline_equals_hand_averaged_gradients():
+@pytest.mark.parametrize("train", [False, True], ids=["eval", "train_dropout_on"])
+def test_two_rank_pipeline_equals_hand_averaged_gradients(train):
+    """train=True: dropout on.  Every rank draws its masks from its own stream (ops.rank_seed: the per-device generators of
+    the reference's DataParallel replicas, train_gen.py:295) -- the two ranks' masks differ -- and the result still equals one
+    process that runs rank 0's and rank 1's step with those ranks' (seed, offset) states and averages the gradients by hand."""
     sys.path.insert(0, ROOT)
-    from gst_visdial_amd import selfcheck as sc
+    from gst_visdial_amd import ops, selfcheck as sc
     from gst_visdial_amd.optim import FusedAdamW
     dev = "cuda:0"
     # ---- reference: one process, gradients of the two batches averaged by hand, plain optimizer step
     model, params, cfg = sc.build_tiny_model("fp32", dev, seed=4)
-    model.eval()
+    model.train(train)
+    model.engine.prepare(torch.device(dev))
+
+    def as_rank(r, k):      # the dropout state rank r holds in front of its step k (no process group here: set it by hand)
+        model.engine.rng.state.copy_(torch.tensor([ops.rank_seed(4, r), k], dtype=torch.int64))
     g = sc.load_npz("tiny_train.npz")
     b0, b1 = _batch(sc, g, ROWS[0], dev), _batch(sc, g, ROWS[1], dev)
     opt = FusedAdamW(model, lr=2e-3)
     ref_losses = []
-    for _ in range(STEPS):
+    for k in range(STEPS):
+        as_rank(0, k)
         l0, _ = model(**b0)
         l0.backward()
         g0 = model.engine.flat.G.clone()
         opt.zero_grad()
+        as_rank(1, k)
         l1, _ = model(**b1)
         l1.backward()
         model.engine.flat.G.add_(g0).mul_(0.5)
@@ -94,7 +108,7 @@ def test_two_rank_pipeline_equals_hand_averaged_gradients():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, train)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
@@ -103,7 +117,10 @@ def test_two_rank_pipeline_equals_hand_averaged_gradients():
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    (r0, l0, p0, n0, s0), (r1, l1, p1, n1, s1) = res
+    (r0, l0, p0, n0, s0, m0, seed0), (r1, l1, p1, n1, s1, m1, seed1) = res
+    assert seed0 == ops.rank_seed(4, 0) == 4 and seed1 == ops.rank_seed(4, 1) != seed0
+    if train:
+        assert m0.shape == m1.shape and (m0 != m1).mean() > 0.2          # independent Bernoulli(0.7) masks differ in ~42 %
     p0, p1 = torch.from_numpy(p0), torch.from_numpy(p1)
     assert n0 == n1 and n0 >= 3 and s0 == s1 == 0.5                  # several slices, 1/N folded into AdamW
     assert torch.equal(p0, p1)                                       # ranks stay bit-identical

@@ -138,20 +138,23 @@ def test_full_model_bf16_close_to_oracle(full_fp32):
     assert (lg.argmax(-1)[clear] == lr.argmax(-1)[clear]).all()
 
 
-def test_bench_shape_step_properties():
-    """configs[1] (16 rows, seq_len 256, bf16, dropout on): finite loss near ln(V) for random weights, identical loss for
-    identical (seed, offset) dropout state, loss changes when the dropout state advances, one AdamW step moves the loss."""
+@pytest.mark.parametrize("rows", [16, 10], ids=["configs1_16rows", "configs2_per_rank_10rows"])
+def test_bench_shape_step_properties(rows):
+    """configs[1] (16 rows, seq_len 256, bf16, dropout on) and configs[2]'s per-rank shape (global 80 on 8 GPUs = 10 rows per
+    rank: M = 2560 / 370 / 250 instead of 4096 / 592 / 400 -- other tile grids, tails and split-K plans): finite loss near ln(V)
+    for random weights, identical loss for identical (seed, offset) dropout state, loss changes when the dropout state
+    advances, one AdamW step moves the loss."""
     import math
     import bench
     from gst_visdial_amd.optim import FusedAdamW
     model, params = bench.build_model(torch.device(DEV), "bf16", seed=3)
     model.train()
     V = model.decoder.config.vocab_size
-    batch = bench.synthetic_rows(16, 256, 37, 25, 2048, V, 99, DEV)
+    batch = bench.synthetic_rows(rows, 256, 37, 25, 2048, V, 99, DEV)
     model(**batch)                                        # builds the engine (flat buffers, rng state)
     st0 = model.engine.rng.state.clone()
     l0, logits = model(**batch)
-    assert logits.shape == (16, 25, V) and torch.isfinite(logits).all()
+    assert logits.shape == (rows, 25, V) and torch.isfinite(logits).all()
     assert abs(l0.item() - math.log(V)) < 1.5
     model.engine.rng.state.copy_(st0)
     l0b, _ = model(**batch)
@@ -220,3 +223,70 @@ def test_full_size_candidate_chunk_properties(full_fp32):
         assert (fast[sub].cpu() - ref).abs().max().item() < 2e-3 * max(1.0, ref.abs().max().item())
     finally:
         model.params["mode"] = mode
+
+
+@pytest.mark.isolated
+def test_full_size_sampling_decode_replay_equals_eager_and_forced_prefix_matches_oracle():
+    """BASELINE configs[3], decode half at FULL size (models/visual_dialog_model.py:74-120 on the 388 M-parameter model, bf16,
+    16 rows x 18 sampled tokens, temperature 0.7 / top_k 7 as generate.py:138-141 sets them):
+      * the hipGraph-replayed call (encoder graph + ONE token-loop graph) returns bit-for-bit the ids of the eagerly issued
+        call under the same uniforms, also when the inputs are new (refreshed in place into the captured buffers);
+      * KV-cached decode == teacher forcing: the call's last-position logits and the engine's teacher-forced pass over the
+        sampled answer (rescore_sampled, which reuses the call's encoder states / cross-attention K/V) equal the CPU oracle's
+        teacher-forced decoder on the same forced prefix, rows 0-1, at the bf16 closeness bar (0.15 on logits ~ +-10)."""
+    import bench
+    from gst_visdial_amd.config import bert_base_enc_config, bert_base_dec_config
+    O = _oracle()
+    dev = torch.device(DEV)
+    model, params = bench.build_model(dev, "bf16", seed=5)
+    model.eval()
+    params["mode"] = "vd_gen_val"
+    V = model.decoder.config.vocab_size
+    Bn, steps = 16, 18
+
+    def inputs(seed):
+        d = bench.synthetic_rows(Bn, 256, 37, 25, 2048, V, seed, dev)
+        return dict(enc_image_features=d["enc_image_features"], enc_image_spatials=d["enc_image_spatials"],
+                    enc_image_mask=d["enc_image_mask"], enc_input_ids=d["enc_input_ids"], enc_segments=d["enc_segments"],
+                    enc_attention_mask=d["enc_attention_mask"],
+                    dec_input_ids=torch.full((Bn, 1), 101, dtype=torch.long, device=dev))
+    args = dict(temperature=0.7, top_k=7, top_p=0.0, ngram_blocking_size=0)
+    u = [torch.rand(steps, Bn, generator=torch.Generator().manual_seed(40 + i)).clamp_min(1e-6).to(dev) for i in range(2)]
+    with torch.no_grad():
+        params["amd_decode_graph"] = False
+        eager = [model(uniforms=u[i], **args, **inputs(70 + i)).clone() for i in range(2)]
+        params["amd_decode_graph"] = True
+        first = model(uniforms=u[0], **args, **inputs(70)).clone()            # eager issue, then captures
+        assert len(model.engine._decode_sessions) == 1
+        replay0 = model(uniforms=u[0], **args, **inputs(70)).clone()          # replay, same inputs
+        replay1 = model(uniforms=u[1], **args, **inputs(71)).clone()          # replay, new inputs + uniforms refreshed in place
+        assert eager[0].shape == (Bn, steps)
+        assert torch.equal(first, eager[0]) and torch.equal(replay0, eager[0]) and torch.equal(replay1, eager[1])
+        assert not torch.equal(eager[0], eager[1])
+        assert int((eager[0] >= V).sum()) == 0 and int((eager[0] < 0).sum()) == 0
+        # ---- forced prefix vs the oracle (rows 0-1 of the second batch)
+        ans = replay1.clone()
+        # two rows that never sampled [SEP] (after it the returned ids are padded while the decode went on with raw tokens)
+        sel = ((ans != 102) & (ans != 0)).all(1).nonzero().flatten()[:2]
+        assert sel.numel() == 2
+        last_logits = model.engine.last["decode_logits"][sel].float().cpu()   # raw logits of the last decode position
+        full = torch.cat((torch.full((Bn, 1), 101, dtype=torch.long, device=dev), ans), dim=1)      # [CLS] + 18 sampled ids
+        forced = full[:, :steps].clone()                                       # decoder input of the last position's pass
+        _, tf_logits = model.engine.rescore_sampled(forced.clone(), None, loss_reduction=False)
+        tf_logits = tf_logits[sel].float().cpu()
+    kw = inputs(71)
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    enc_cfg, dec_cfg = bert_base_enc_config(), bert_base_dec_config()
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    sel = sel.cpu()
+    cpu = {k: v.cpu()[sel] for k, v in kw.items()}
+    enc_t, enc_v = O.encoder_forward(sd, enc_cfg, cpu["enc_input_ids"], cpu["enc_segments"], cpu["enc_attention_mask"],
+                                     cpu["enc_image_features"], cpu["enc_image_spatials"], cpu["enc_image_mask"], False)
+    enc_h, enc_mask = O.vl_fusion(sd, enc_t, enc_v, cpu["enc_attention_mask"], cpu["enc_image_mask"], False)
+    # the sampling branch feeds the raw prefix (no eos->pad mutation, no padding mask: visual_dialog_model.py:86-95)
+    y = O.decoder_hidden(sd, dec_cfg, forced.cpu()[sel], None, enc_h, enc_mask, False)
+    ref = O.lm_logits(sd, y)                                                   # [2, 18, V], position t from prefix[:t+1]
+    assert (last_logits - ref[:, -1]).abs().max().item() < 0.15
+    # rescore_sampled applies the labels=None conventions (eos -> pad in the decoder input) -- restate them for the oracle
+    # (rescore_sampled applies the labels=None conventions -- eos -> pad in the decoder input --, a no-op on these rows)
+    assert (tf_logits - ref).abs().max().item() < 0.15

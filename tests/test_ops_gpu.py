@@ -532,10 +532,14 @@ def test_decode_layernorm_folded_into_the_linear(M, N, K):
     assert (yo.float() - yn.float()).abs().max().item() <= 2.0 ** -7 * max(1.0, yn.float().abs().max().item())
     check("gemv_ln", c.contiguous(), ref, torch.bfloat16, 2.0)
     assert float(big[:, 0].abs().max()) == 0.0 and float(big[:, 2].abs().max()) == 0.0
-    r = rnd(M, N, dtype=torch.bfloat16, seed=65)
+    r = rnd(M, N, seed=65)                                           # the addend has the OUTPUT's type (fp32 here), as in gstvd_gemm
     c2 = torch.empty(M, N, device=DEV, dtype=torch.float32)
     o.gemv_ln(x, w, c2, M, N, K, gam, bet, 1e-12, bias=b, addend=r)
-    check("gemv_ln_add_f32out", c2, ref + r.float(), torch.bfloat16, 2.0)
+    check("gemv_ln_add_f32out", c2, ref + r, torch.bfloat16, 2.0)
+    rb = r.to(torch.bfloat16)
+    c3 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    o.gemv_ln(x, w, c3, M, N, K, gam, bet, 1e-12, bias=b, addend=rb)
+    check("gemv_ln_add_bf16out", c3, ref + rb.float(), torch.bfloat16, 2.0)
     a, u = torch.empty(M, N, device=DEV, dtype=torch.bfloat16), torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
     o.gemv_ln(x, w, a, M, N, K, gam, bet, 1e-12, bias=b, aux=u, epi=o.EPI_GELU)
     check("gemv_ln_gelu", a, torch.nn.functional.gelu(ref), torch.bfloat16, 2.0)

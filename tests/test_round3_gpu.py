@@ -306,18 +306,18 @@ def test_checkpoint_after_graph_replays_records_the_device_step_count_and_resume
     assert sd["opt_step"] == done + 4                      # (round 2: stuck at the host's count)
     ref = opt.export_reference_state()
     assert all(int(v["step"]) == done + 4 for v in ref["state"].values()) and len(ref["state"]) > 100
-    for fmt in (False, True):
-        path = str(tmp_path / ("ck_%d.pt" % fmt))
+    paths = {fmt: str(tmp_path / ("ck_%d.pt" % fmt)) for fmt in (False, True)}
+    for fmt, path in paths.items():
         save_checkpoint(path, model, opt, iter_id=done + 4, reference_format=fmt)
+    replay(); replay()                                     # the uninterrupted run goes on; both resumes are compared against it
+    torch.cuda.synchronize()
+    want = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    for fmt, path in paths.items():
         m2, o2, step2 = make()
         load_checkpoint(path, m2, o2)
         for _ in range(2):
             step2()
         torch.cuda.synchronize()
-        if not fmt:                                        # continue the original once, compare both resumes against it
-            replay(); replay()
-            torch.cuda.synchronize()
-            want = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
         got = m2.state_dict()
         worst = max((got[k].float().cpu() - want[k]).abs().max().item() for k in want)
         assert worst < 2e-6, (fmt, worst)
