@@ -233,7 +233,11 @@ def main():
         # six-slice list 128, 48, 48, 32, 32, 24 of round 1 -- fewer, larger grouped launches; the last two slices stay small)
         chunk_elems = [c << 20 for c in (128, 96, 96, 32, 16)]
     else:
-        chunk_elems = 192 << 20
+        # N = 1: the decoder's gradients are finished in small slices DURING its own latency-bound backward (the LM head first,
+        # then three decoder layers at a time: weight-gradient GEMMs + AdamW run beside a chain that leaves two thirds of the
+        # CUs idle), the encoder's in one large slice at the end (beside the encoder's throughput-bound backward smaller slices
+        # only move time around).  tools/chunk_sweep.sh, profiles/r03_chunk_sweep.txt: 13.87 vs 14.15-14.2 ms for [192, rest].
+        chunk_elems = [c << 20 for c in (22, 27, 27, 27, 27, 192)]
     pipe = None if args.no_pipeline else BackwardPipeline(model.engine, optimizer=opt, chunk_elems=chunk_elems,
                                                           compress=compress, force_collective=force_dist)
 
