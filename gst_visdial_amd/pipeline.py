@@ -40,7 +40,13 @@ class BackwardPipeline(object):
         self._bufs, self.comm, self.tail_event = {}, None, None
         import os
         self.use_comm_stream = os.environ.get("GSTVD_PIPE_COMM", "1") != "0"
-        self.update_stream = os.environ.get("GSTVD_PIPE_UPDATE_STREAM", "0") != "0"
+        # N = 1: a slice's AdamW (HBM-bound) runs on a stream of its own, beside the NEXT slice's weight-gradient GEMMs
+        # (MFMA-bound) and the rest of backward.  Zero-sum with round 2's two large slices; with the decoder's gradients finished
+        # in small slices during its own backward it is worth 0.35 ms per step (tools/chunk_sweep.sh: 13.65 vs 14.00 ms)
+        self.update_stream = os.environ.get("GSTVD_PIPE_UPDATE_STREAM", "1") != "0"
+        # the last slice (after backward's last kernel) is cut into this many parts: AdamW of part j beside the weight gradients
+        # of part j+1 (engine._emit); only with the update stream, i.e. without a collective
+        self.tail_parts = int(os.environ.get("GSTVD_PIPE_TAIL_PARTS", "3"))
         if optimizer is not None:
             optimizer.grad_scale = 1.0 / self.world
         engine.pipe = self
@@ -72,6 +78,9 @@ class BackwardPipeline(object):
         hipStreamEndCapture on this stack: a forked stream may only be joined into the capture's origin stream.)"""
         flat = self.engine.flat
         self.slices.append((lo, hi))
+        if hi <= lo:
+            self.hi = lo
+            return
         sl = flat.G[lo:hi]
         if not self.collective:
             if self.update_stream and sl.is_cuda and self.opt is not None:

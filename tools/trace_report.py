@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Report on one replayed train step from a rocprofv3 kernel trace (tools/trace_step.sh): per-queue span / busy time, phase
 boundaries, time by number of kernels in flight, every interval with NO kernel running named by the kernels around it,
-the memcpy / memset nodes of the graph, and the per-kernel totals.   usage: trace_report.py TRACE.csv[.gz] [min_gap_us=8]"""
+the memcpy / memset nodes of the graph, and the per-kernel totals.   usage: trace_report.py TRACE.csv[.gz] [min_gap_us=8] [step index]"""
 import collections, csv, gzip, io, re, sys
 
 path = sys.argv[1]
@@ -9,7 +9,21 @@ min_gap = float(sys.argv[2]) if len(sys.argv) > 2 else 8.0
 fh = gzip.open(path, "rt") if path.endswith(".gz") else open(path)
 rows = sorted(csv.DictReader(fh), key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "rng_advance" in r["Kernel_Name"]]
-a, b = idx[-2], idx[-1]
+# Steady-state replays only: the first steps of the trace are eager warm-up / capture, and the LAST complete step is the end of
+# the timed burst (nothing queued behind it: round 2's timeline reported that one, with 1.2 ms of idle time and a 0.3 ms tail
+# that the back-to-back replays in front of it do not have).  Report the median-length step among the ones that are followed by
+# another replay, and list all of them.
+spans = []
+for k in range(len(idx) - 1):
+    st = rows[idx[k]:idx[k + 1]]
+    spans.append((max(int(r["End_Timestamp"]) for r in st) - int(st[0]["Start_Timestamp"]), k))
+steady = [(sp, k) for sp, k in spans[:-1] if sp < 1.5 * min(s_ for s_, _ in spans)]
+print("replayed steps followed by another replay: " + "  ".join("#%d %.3f ms (next starts +%.3f)" % (
+    k, sp / 1e6, (int(rows[idx[k + 1]]["Start_Timestamp"]) - int(rows[idx[k]]["Start_Timestamp"])) / 1e6) for sp, k in steady))
+pick = sorted(steady)[len(steady) // 2][1] if steady else len(idx) - 2
+if len(sys.argv) > 3:
+    pick = int(sys.argv[3])
+a, b = idx[pick], idx[pick + 1]
 step = rows[a:b]
 t0 = int(step[0]["Start_Timestamp"])
 t1 = max(int(r["End_Timestamp"]) for r in step)
