@@ -443,49 +443,23 @@ class Engine(object):
         if off == 0 and self.use_streams:
             # the last slice, after backward's last kernel: the main stream has nothing left to do, so the slice's column
             # reductions run there, beside its grouped weight-gradient launch on the auxiliary stream (which then waits for them).
-            # Nothing else is left to overlap this slice's MFMA-bound weight gradients (~1 ms) and HBM-bound AdamW (~1.1 ms) with
-            # -- except each other: the slice is cut into `pipe.tail_parts` sub-ranges, AdamW of part j (on the update stream)
-            # runs beside the weight-gradient launch of part j+1 (on the auxiliary stream).
-            parts = self._tail_parts(self.pipe.hi)
-            base = self.flat.G.data_ptr()
+            # (Round 3 measured cutting this slice into 2-6 parts so that AdamW of part j runs beside the weight gradients of part
+            # j+1, also with the weight-gradient launch confined to 160-224 CUs: 13.73-14.01 ms against 13.72 ms, resp. +0.3 ms --
+            # the two full-chip kernels do not share the chip profitably; profiles/r03_chunk_sweep.txt.  Not kept.)
             with torch.cuda.stream(self.aux):
-                self.wgrads.flush_range(base + 4 * parts[0][0], base + 4 * parts[0][1])
+                self.wgrads.flush()
             self.colsums.flush()
             ev = torch.cuda.Event()
             ev.record(self.main)
             self.aux.wait_event(ev)
             with torch.cuda.stream(self.aux):
-                for j, (a, b) in enumerate(parts):
-                    if j:
-                        self.wgrads.flush_range(base + 4 * a, base + 4 * b)
-                    self.pipe.run_slice(a, b)
-                self.wgrads.flush()              # (nothing should be left; never lose a queued gradient)
+                self.pipe.run_slice(off, self.pipe.hi)
         else:
             with torch.cuda.stream(self.aux):
                 self.wgrads.flush()
                 self.colsums.flush()
                 self.pipe.run_slice(off, self.pipe.hi)
         self.aux_busy = True
-
-    def _tail_parts(self, hi):
-        """[(lo, hi)] sub-ranges of the last slice [0, hi), highest first, cut at starts of queued weight gradients so that no
-        grouped problem straddles a cut; `pipe.tail_parts` parts of about equal size (1 = the whole slice at once)."""
-        pipe = self.pipe
-        k = int(getattr(pipe, "tail_parts", 1) or 1)
-        if getattr(pipe, "collective", False) or not getattr(pipe, "update_stream", False) or getattr(pipe, "opt", None) is None:
-            k = 1                                   # (a collective per part, or nothing to overlap the parts with)
-        if k <= 1 or hi <= 0:
-            return [(0, hi)]
-        base = self.flat.G.data_ptr()
-        starts = sorted(set((p - base) // 4 for p in self.wgrads.c_starts() if 0 <= (p - base) // 4 < hi))
-        cuts = []
-        for j in range(1, k):
-            want = hi * j // k
-            best = min(starts, key=lambda s_: abs(s_ - want)) if starts else None
-            if best is not None and 0 < best < hi and best not in cuts:
-                cuts.append(best)
-        edges = [0] + sorted(cuts) + [hi]
-        return [(edges[i], edges[i + 1]) for i in range(len(edges) - 2, -1, -1)]
 
     # -- two HIP streams: the vision stream's skinny (M = B*37) kernels run beside the text stream's --------------
     class _On(object):

@@ -254,26 +254,6 @@ class GemmGroup(object):
     def reset(self):
         self.items, self.keep = [], []
 
-    def c_starts(self):
-        """Device addresses of the queued problems' outputs (sorted, unique)."""
-        return sorted(set(it[2] for it in self.items))
-
-    def flush_range(self, lo_ptr, hi_ptr):
-        """Launch only the queued problems whose OUTPUT starts inside [lo_ptr, hi_ptr) (the weight gradients of one sub-range of
-        the flat gradient buffer); the others stay queued, in order."""
-        sel = [i for i, it in enumerate(self.items) if lo_ptr <= it[2] < hi_ptr]
-        if not sel:
-            return
-        pick = set(sel)
-        rest_items = [it for i, it in enumerate(self.items) if i not in pick]
-        rest_keep = [k for i, k in enumerate(self.keep) if i not in pick]
-        self.items = [self.items[i] for i in sel]
-        self.keep = [self.keep[i] for i in sel]
-        try:
-            self.flush()
-        finally:
-            self.items, self.keep = rest_items, rest_keep
-
     def flush(self):
         if not self.items:
             return

@@ -44,9 +44,6 @@ class BackwardPipeline(object):
         # (MFMA-bound) and the rest of backward.  Zero-sum with round 2's two large slices; with the decoder's gradients finished
         # in small slices during its own backward it is worth 0.35 ms per step (tools/chunk_sweep.sh: 13.65 vs 14.00 ms)
         self.update_stream = os.environ.get("GSTVD_PIPE_UPDATE_STREAM", "1") != "0"
-        # the last slice (after backward's last kernel) is cut into this many parts: AdamW of part j beside the weight gradients
-        # of part j+1 (engine._emit); only with the update stream, i.e. without a collective
-        self.tail_parts = int(os.environ.get("GSTVD_PIPE_TAIL_PARTS", "3"))
         if optimizer is not None:
             optimizer.grad_scale = 1.0 / self.world
         engine.pipe = self

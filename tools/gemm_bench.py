@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Back-to-back timing + correctness of the step's main GEMM shapes through the C ABI (bf16 in/out; tn: fp32 out).
-usage: gemm_bench.py [set]   set in: main (default) | small | all.  Tuning env vars (GSTVD_GEMM_*) apply."""
+usage: gemm_bench.py [set] [lib]   set in: main (default) | small | all.  Tuning env vars (GSTVD_GEMM_*) apply.
+`lib`: also time torch.matmul (the vendor BLAS behind it) on the same operands -- a speed-of-light REFERENCE for the tile design,
+never a code path of the product (which has no BLAS call)."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
@@ -29,8 +31,20 @@ def run(lay, M, N, K, reps=30):
     for _ in range(reps): ops.gemm(A, B, C, M, N, K, a_km=a_km, b_km=b_km)
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
-    print("%s %5dx%5dx%5d %-22s %7.1f us  %6.1f TFLOP/s  relerr %.1e%s" % (lay, M, N, K, ops.gemm_tag(1, a_km, b_km, M, N, 1), us,
-          2.0 * M * N * K / us / 1e6, err, "  <-- WRONG" if err > 2e-2 else ""))
+    lib = ""
+    if len(sys.argv) > 2 and sys.argv[2] == "lib":
+        Am = A.t() if a_km else A
+        Bm = B if b_km else B.t()
+        out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        for _ in range(3): torch.matmul(Am, Bm, out=out)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps): torch.matmul(Am, Bm, out=out)
+        e1.record(); torch.cuda.synchronize()
+        ul = e0.elapsed_time(e1) * 1e3 / reps
+        lib = "   | vendor BLAS (torch.matmul, bf16 out) %7.1f us %6.1f TFLOP/s" % (ul, 2.0 * M * N * K / ul / 1e6)
+    print("%s %5dx%5dx%5d %-22s %7.1f us  %6.1f TFLOP/s  relerr %.1e%s%s" % (lay, M, N, K, ops.gemm_tag(1, a_km, b_km, M, N, 1), us,
+          2.0 * M * N * K / us / 1e6, err, "  <-- WRONG" if err > 2e-2 else "", lib))
 which = sys.argv[1] if len(sys.argv) > 1 else "main"
 for sh in (MAIN if which == "main" else SMALL if which == "small" else MAIN + SMALL):
     run(*sh)
