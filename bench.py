@@ -161,7 +161,7 @@ def main():
                          "with the step and a failed capture is a hard error; off: eager issue, host bound)")
     ap.add_argument("--no-pipeline", action="store_true", help="diagnostic: no backward pipeline (wgrad/AdamW after backward, same stream)")
     ap.add_argument("--chunk-melems", type=int, default=0,
-                    help="backward-pipeline slice size in Mi elements (0 = auto: 192 at N=1; graded 128,96,96,32,16 at N>1)")
+                    help="backward-pipeline slice size in Mi elements (0 = auto: 192 at N=1; graded 22,27,27,27,27,96,96,32,16 at N>1)")
     ap.add_argument("--chunk-list", default="", help="graded backward-pipeline slice sizes in Mi elements, comma separated (overrides --chunk-melems)")
     ap.add_argument("--no-streams", action="store_true", help="run the vision stream on the main HIP stream")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 parity-mode timing beside the bf16 headline")
@@ -231,7 +231,11 @@ def main():
         # ones so that the exposed tail after backward (last slice's wgrad + all-reduce + AdamW) stays short
         # (tools/dist_slice_sweep.sh on the 1-rank RCCL path: 14.28 / 12.37 ms at 16 / 10 rows against 14.80 / 12.81 ms for the
         # six-slice list 128, 48, 48, 32, 32, 24 of round 1 -- fewer, larger grouped launches; the last two slices stay small)
-        chunk_elems = [c << 20 for c in (128, 96, 96, 32, 16)]
+        # round 3: the decoder's part goes out in five small slices DURING its own backward (LM head, then three decoder layers
+        # at a time) instead of one 128 Mi slice at its end -- the first all-reduce starts ~2 ms earlier and the weight-gradient /
+        # AdamW work of those slices runs beside a latency-bound chain: 14.04 vs 14.28 ms on the 1-rank RCCL path
+        # (profiles/r03_chunk_sweep.txt); messages stay >= 44 MB (bf16), large enough for a point-to-point xGMI ring
+        chunk_elems = [c << 20 for c in (22, 27, 27, 27, 27, 96, 96, 32, 16)]
     else:
         # N = 1: the decoder's gradients are finished in small slices DURING its own latency-bound backward (the LM head first,
         # then three decoder layers at a time: weight-gradient GEMMs + AdamW run beside a chain that leaves two thirds of the
