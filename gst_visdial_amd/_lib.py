@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgstvd_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 F32, BF16 = 0, 1
 EPI_BIAS, EPI_ADD, EPI_GELU, EPI_DGELU, EPI_DROPOUT = 1, 2, 4, 8, 16
@@ -86,6 +86,9 @@ SIGNATURES = {
     "gstvd_ln_bwd_blocks": (_i64, [_i64]),
     "gstvd_ln_bwd_blocks_for": (_i64, [_i64, _i64, _i32]),
     "gstvd_ln_bwd": (_i32, [C.POINTER(LnBwdDesc), _vp]),
+    "gstvd_gemm_ln_fwd": (_i32, [C.POINTER(GemmDesc), C.POINTER(LnDesc), _vp]),
+    "gstvd_gemm_ln_bwd": (_i32, [C.POINTER(GemmDesc), C.POINTER(LnBwdDesc), _vp]),
+    "gstvd_gemm_ln_rows_per_block": (_i64, []),
     "gstvd_colsum_partials": (_i32, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _i32, _vp]),
     "gstvd_colsum_batched": (_i32, [_vp, _i64, _i64, _vp]),
     "gstvd_colsum_slabs_batched": (_i32, [_vp, _i64, _i64, _i32, _vp]),

@@ -39,11 +39,12 @@ def _round_up(x, m):
 
 class Act(object):
     """An activation [M, N] in the arena plus (during backward) its gradient."""
-    __slots__ = ("t", "g", "M", "N", "gelu_aux", "bias_done")
+    __slots__ = ("t", "g", "M", "N", "gelu_aux", "bias_done", "prod", "dgrad_done")
 
     def __init__(self, t, M, N):
         self.t, self.g, self.M, self.N = t, None, M, N
         self.gelu_aux, self.bias_done = None, False
+        self.prod, self.dgrad_done = None, False      # the Linear that produced it (input, weight, K_in, need_dx); see _ln_bwd
 
 
 class Arena(object):
@@ -314,6 +315,8 @@ class Engine(object):
         self.stats = {}
         self._validate = True
         self.use_streams = bool(params.get("amd_streams", True))
+        # LayerNorm folded into the Linear next to it for latency-bound row counts (the decoder: csrc/gemm_rows.hip)
+        self.fuse_ln = (prec == "bf16" and bool(params.get("amd_fuse_ln", True)) and os.environ.get("GSTVD_FUSE_LN", "1") != "0")
         self.tag = "t"
 
     @property
@@ -518,8 +521,34 @@ class Engine(object):
             y.gelu_aux = u
         else:
             ops.gemm(x.t, self.W[w], y.t, x.M, N, K, bias=self.Pv[b])
+        y.prod = (x, w, K, need_dx)
         self.push(lambda: self._lin_bwd(x, y, w, b, N, K, need_dx))
         return y
+
+    def ln_lin(self, x, res, g, b, H, p_pre, bias_name, eps, w, wb, N, gelu=False, mark=None):
+        """y = LN(drop(x) + res); out = Linear_w(y) (+ GELU): ONE launch when the rows are few enough that every launch is
+        latency bound (gstvd_gemm_ln_fwd; the decoder's ln1 -> cross-attention query, ln2 -> FFN up, ln3 -> next layer's
+        QKV), else the two kernels.  `mark`: a pipeline watermark that belongs between the two (the LayerNorm's parameters
+        sit in the previous layer's slice of the flat buffer, the Linear's in the next one's).  Returns (y, out)."""
+        M = x.M
+        if not (self.fuse_ln and res is not None and ops.gemm_ln_ok(M, N, H, self.adt)):
+            y = self.ln(x, res, g, b, H, p_pre, bias_name, eps)
+            if mark is not None:
+                self.mark(mark)
+            return y, self.lin(y, w, wb, N, H, gelu=gelu)
+        y, out = self.act(M, H), self.act(M, N)
+        kw = dict(mode=LN_RESID, dtype=ops.dt(x.t), M=M, H=H, gamma=self.Pv[g], beta=self.Pv[b],
+                  mean=self.vec(M), rstd=self.vec(M), eps=eps, x=x.t, res=res.t, y=y.t,
+                  p_pre=p_pre if self.train else 0.0, site_pre=self.site(g[:-2], p_pre, "rows", (M, H)), rng=self.rng)
+        aux = self.buf(M, N) if gelu else None
+        ops.gemm_ln_fwd(kw, self.W[w], out.t, N, bias=self.Pv[wb], aux=aux, epi=EPI_GELU if gelu else 0)
+        out.gelu_aux = aux
+        out.prod = (y, w, H, True)
+        self.push(lambda: self._ln_bwd(kw, x, res, y, g, b, H, bias_name))
+        if mark is not None:
+            self.mark(mark)
+        self.push(lambda: self._lin_bwd(y, out, w, wb, N, H, True))
+        return y, out
 
     def _lin_bwd(self, x, y, w, b, N, K, need_dx):
         dy, M = y.g, x.M      # for a GELU output y.g already holds d(pre-activation): its producer applied gelu'
@@ -535,7 +564,7 @@ class Engine(object):
                 gb, accb = self.grad_slot(b)
                 scratch = self.vec(((M + 63) // 64) * N)
                 self.colsums.add_slabs(dy, M, N, scratch, gb, accb)
-        if need_dx:
+        if need_dx and not y.dgrad_done:          # (dgrad_done: the LayerNorm behind y ran it with its own backward, _ln_bwd)
             add = x.g
             if x.g is None:
                 x.g = self.buf(M, K)
@@ -565,6 +594,28 @@ class Engine(object):
 
     def _ln_bwd(self, kw, x, res, y, g, b, H, bias_name):
         M = x.M
+        prod = x.prod
+        if (self.fuse_ln and prod is not None and prod[3] and res is not None and prod[0].N == prod[2]
+                and ops.gemm_ln_ok(M, prod[2], H, x.t.dtype)):
+            # the LayerNorm's backward and the input gradient of the Linear that produced its input, one launch
+            # (gstvd_gemm_ln_bwd): dx never travels through HBM between the two, one dependent launch less per sub-layer
+            xin, w, Kin, _ = prod
+            R = ops.gemm_ln_rows()
+            nblk = (M + R - 1) // R
+            partial = self.arena.alloc(nblk * 3 * H, torch.float32)
+            if res.g is not None:
+                raise GstvdError("internal: residual gradient written twice")
+            res.g = self.buf(M, H)
+            x.g = self.buf(M, H)
+            add = xin.g
+            if xin.g is None:
+                xin.g = self.buf(M, Kin)
+            ops.gemm_ln_bwd(kw, y.g, partial, nblk, self.W[w], xin.g, Kin, dres=res.g, dx=x.g, addend=add, aux=xin.gelu_aux,
+                            epi=EPI_DGELU if xin.gelu_aux is not None else 0)
+            x.dgrad_done = True
+            self._colsums(partial, nblk, H, [g, b, bias_name])
+            x.bias_done = bias_name is not None
+            return
         nblk = ops.ln_bwd_blocks(M, H, LN_RESID)
         partial = self.arena.alloc(nblk * 3 * H, torch.float32)
         if res is not None:
@@ -778,24 +829,36 @@ class Engine(object):
         # hidden_dropout_prob (vilbert_dialog.py:321), whoever calls it (tests/golden/tiny_train_dropout.npz)
         y = self.embed("emb" if shared else "demb", I["dec_ids"], None, Bn, U, c, label="emb.dec",
                        p_drop=self.enc_cfg.hidden_dropout_prob if shared else None)
+        # Each of the three LayerNorms of a layer is issued together with the Linear that reads it (ln_lin: one launch at the
+        # decoder's row counts) -- ln3 with the NEXT layer's QKV projection, hence `pend`; its backward runs with the input
+        # gradient of the Linear in front of it (_ln_bwd).  8 launches per layer and direction instead of 11.
+        pend = None                                   # (fo, y2, prefix) of the previous layer: its ln3 is still to be issued
         for i in range(L):
             p = "d%d" % i
-            self.mark(("d", i))
-            qkv = self.lin(y, p + ".qkv.w", p + ".qkv.b", 3 * H, H)
+            if pend is None:
+                self.mark(("d", i))
+                qkv = self.lin(y, p + ".qkv.w", p + ".qkv.b", 3 * H, H)
+            else:
+                fo_, y2_, pp = pend
+                y, qkv = self.ln_lin(fo_, y2_, pp + ".ln3.w", pp + ".ln3.b", H, c.hidden_dropout_prob, pp + ".fo.b", eps,
+                                     p + ".qkv.w", p + ".qkv.b", 3 * H, mark=("d", i))
             ctx = self.attn((qkv, 0), (qkv, H), (qkv, 2 * H), Bn, nh, U, U, d, I["dmask"], True, -10000.0,
                             c.attention_probs_dropout_prob, label=p + ".attn")
             ao = self.lin(ctx, p + ".ao.w", p + ".ao.b", H, H)
-            y1 = self.ln(ao, y, p + ".ln1.w", p + ".ln1.b", H, c.hidden_dropout_prob, p + ".ao.b", eps)
-            q = self.lin(y1, p + ".cq.w", p + ".cq.b", H, H)
+            y1, q = self.ln_lin(ao, y, p + ".ln1.w", p + ".ln1.b", H, c.hidden_dropout_prob, p + ".ao.b", eps,
+                                p + ".cq.w", p + ".cq.b", H)
             if kv_on_side and i == 0:
                 self.sync("t", "v")               # the first cross-attention needs the K/V projection
             ctx = self.attn((q, 0), (kv, 2 * i * H), (kv, (2 * i + 1) * H), Bn, nh, U, S, d, I["emask"], False, -1e9,
                             c.attention_probs_dropout_prob, kv_group=kv_group, label=p + ".xattn")
             co = self.lin(ctx, p + ".co.w", p + ".co.b", H, H)
-            y2 = self.ln(co, y1, p + ".ln2.w", p + ".ln2.b", H, c.hidden_dropout_prob, p + ".co.b", eps)
-            a = self.lin(y2, p + ".fi.w", p + ".fi.b", c.intermediate_size, H, gelu=True)
+            y2, a = self.ln_lin(co, y1, p + ".ln2.w", p + ".ln2.b", H, c.hidden_dropout_prob, p + ".co.b", eps,
+                                p + ".fi.w", p + ".fi.b", c.intermediate_size, gelu=True)
             fo = self.lin(a, p + ".fo.w", p + ".fo.b", H, c.intermediate_size)
-            y = self.ln(fo, y2, p + ".ln3.w", p + ".ln3.b", H, c.hidden_dropout_prob, p + ".fo.b", eps)
+            pend = (fo, y2, p)
+        if pend is not None:
+            fo_, y2_, pp = pend
+            y = self.ln(fo_, y2_, pp + ".ln3.w", pp + ".ln3.b", H, c.hidden_dropout_prob, pp + ".fo.b", eps)
         self.mark("lm")
         logits = self.lin(y, "lm.w", "lm.b", self.flat.Vp, H)
         return y, logits

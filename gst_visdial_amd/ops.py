@@ -593,3 +593,68 @@ def adamw(param, grad, m, v, shadow, seg_end, hp, step, beta1=0.9, beta2=0.999, 
         L.check("gstvd_adamw", lib.gstvd_adamw(_p(param), _p(grad), _p(m), _p(v), _p(shadow), n, _p(seg_end), _p(hp),
                                                seg_end.numel(), beta1, beta2, eps, _p(step), grad_scale, begin, _stream()))
     _prof_end(e0, "adamw", 0.0, (n - begin) * (30.0 if shadow is not None else 28.0))
+
+
+def gemm_ln_rows():
+    """Rows per block of the LayerNorm-folded GEMMs (their backward writes one [3][H] partial slab per block)."""
+    return int(L.load().gstvd_gemm_ln_rows_per_block())
+
+
+def _gemm_desc_noA(B, C_out, M, N, K, b_km, bias, addend, aux, epi):
+    d = L.GemmDesc()
+    d.A, d.B, d.C = None, _p(B), _p(C_out)
+    d.bias, d.addend, d.aux = _p(bias), _p(addend), _p(aux)
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc = 0, B.stride(-2), C_out.stride(-2)
+    d.ldadd = addend.stride(-2) if addend is not None else 0
+    d.ldaux = aux.stride(-2) if aux is not None else 0
+    d.batch, d.dtype_in, d.dtype_out, d.alpha = 1, dt(B), dt(C_out), 1.0
+    d.a_kmajor, d.b_kmajor = 0, int(b_km)
+    if bias is not None:
+        epi |= EPI_BIAS
+    if addend is not None:
+        epi |= EPI_ADD
+    d.epilogue = epi
+    return d
+
+
+def gemm_ln_fwd(ln_kw, B, C_out, N, *, b_km=False, bias=None, addend=None, aux=None, epi=0):
+    """C[M, N] = epi(LN(ln_kw) . B^T) in ONE launch (gstvd_gemm_ln_fwd); also writes ln_kw['y'] / mean / rstd as ln_fwd would.
+    Raises GstvdError(GSTVD_E_UNSUPPORTED) for shapes outside the kernel's range -- callers check `gemm_ln_ok` first."""
+    lib = L.load()
+    ld = _ln_desc(**ln_kw)
+    d = _gemm_desc_noA(B, C_out, ld.M, N, ld.H, b_km, bias, addend, aux, epi)
+    e0 = _prof_begin()
+    L.check("gstvd_gemm_ln_fwd", lib.gstvd_gemm_ln_fwd(C.byref(d), C.byref(ld), _stream()))
+    _prof_end(e0, "gemm_ln_fwd", 2.0 * ld.M * N * ld.H, float(3 * ld.M * ld.H * 2 + N * ld.H * 2 + ld.M * N * C_out.element_size()),
+              (ld.M, N, ld.H, 1))
+    return C_out
+
+
+def gemm_ln_bwd(ln_kw, dy, partial, nblk, B, C_out, N, *, dres=None, dx=None, b_km=True, addend=None, aux=None, epi=0):
+    """C[M, N] = epi(dx . B) with dx = the LayerNorm backward of ln_kw under dy, in ONE launch (gstvd_gemm_ln_bwd); also writes
+    dres, dx and the [nblk, 3, H] column partials (nblk = ceil(M / gemm_ln_rows()))."""
+    lib = L.load()
+    b = L.LnBwdDesc()
+    b.f = _ln_desc(**ln_kw)
+    b.nblk = nblk
+    b.dy, b.lddy = _p(dy), dy.stride(-2)
+    b.dres, b.lddres = _p(dres), (dres.stride(-2) if dres is not None else 0)
+    b.dx, b.lddx = _p(dx), (dx.stride(-2) if dx is not None else 0)
+    b.partial = _p(partial)
+    d = _gemm_desc_noA(B, C_out, b.f.M, N, b.f.H, b_km, None, addend, aux, epi)
+    e0 = _prof_begin()
+    L.check("gstvd_gemm_ln_bwd", lib.gstvd_gemm_ln_bwd(C.byref(d), C.byref(b), _stream()))
+    _prof_end(e0, "gemm_ln_bwd", 2.0 * b.f.M * N * b.f.H, float(5 * b.f.M * b.f.H * 2 + N * b.f.H * 2 + b.f.M * N * C_out.element_size()),
+              (b.f.M, N, b.f.H, 1))
+    return C_out
+
+
+def gemm_ln_ok(M, N, H, dtype):
+    """Shapes the LayerNorm-folded GEMMs take (csrc/gemm_rows.hip): bf16, H = K a multiple of 64 up to 768, up to 640 rows
+    (beyond that the plain kernels' larger tiles win), at least five 128-column tiles."""
+    if not (dtype == torch.bfloat16 and H % 64 == 0 and H <= 768 and M <= 640 and N >= 640 and N % 8 == 0):
+        return False
+    # one round of the chip: two workgroups (16 rows x 128 columns) fit a CU; beyond 512 the second round doubles the launch
+    # (N = 3072 at 400 rows: 22 us forward / 38 us backward against 23 / 26 us for the two separate kernels)
+    return ((M + 15) // 16) * ((N + 127) // 128) <= 512

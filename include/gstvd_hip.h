@@ -138,6 +138,22 @@ int64_t gstvd_ln_bwd_blocks(int64_t M);                                    /* up
 int64_t gstvd_ln_bwd_blocks_for(int64_t M, int64_t H, int32_t mode);       /* the geometry gstvd_ln_bwd uses when told so via nblk */
 int gstvd_ln_bwd(const gstvd_ln_bwd_t* p, gstvd_stream_t s);
 
+/* LayerNorm folded into the Linear next to it, for latency-bound row counts (the decoder's M = rows x 25; csrc/gemm_rows.hip).
+ * Both take a gstvd_gemm_t whose A operand is NOT read (A is produced in the kernel; M, K = the LayerNorm's M, H; bf16 operands,
+ * batch 1, row-major or k-major B, every gstvd_gemm epilogue flag except COLSUM) and a RESID-mode LayerNorm descriptor:
+ *   gstvd_gemm_ln_fwd   C = epi( LN(drop(x) + res) . B^T );  also writes ln->y / mean / rstd exactly as gstvd_ln_fwd would
+ *                       (BertSelfOutput / BertOutput LayerNorm + the dense that reads it: transformers 4.16.2 modeling_bert,
+ *                       call sites models/visual_dialog_decoder.py:300-311)
+ *   gstvd_gemm_ln_bwd   C = epi( dx . B ), dx = what gstvd_ln_bwd(lb) writes to lb->dx (the LayerNorm's backward + the input
+ *                       gradient of the Linear that produced the LayerNorm's input; autograd of the same modules); also writes
+ *                       lb->dres, lb->dx and lb->partial = [ceil(M/R), 3, H] column partials, R = gstvd_gemm_ln_rows_per_block();
+ *                       lb->nblk must be ceil(M/R)
+ * Constraints: H = K a multiple of 64 and <= 768, M <= 1024, N >= 640 and N % 8 == 0.  GSTVD_E_UNSUPPORTED otherwise (the caller
+ * runs the two kernels separately). */
+int gstvd_gemm_ln_fwd(const gstvd_gemm_t* g, const gstvd_ln_t* ln, gstvd_stream_t s);
+int gstvd_gemm_ln_bwd(const gstvd_gemm_t* g, const gstvd_ln_bwd_t* lb, gstvd_stream_t s);
+int64_t gstvd_gemm_ln_rows_per_block(void);
+
 /* out_j[c] (+)= sum_blk partial[blk, j, c]  for j in 0..nvec-1 ; out_j may be NULL (skipped) */
 int gstvd_colsum_partials(const float* partial, int64_t nblk, int64_t nvec, int64_t H,
                           float* out0, float* out1, float* out2, int32_t accumulate, gstvd_stream_t s);

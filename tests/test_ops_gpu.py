@@ -698,3 +698,96 @@ def test_skinny_decode_gemm(M, N, K, out):
     d.A, d.B, d.C, d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.batch = x.data_ptr(), w.data_ptr(), y.data_ptr(), M, N, K, K, K, 3 * N, 1
     d.dtype_in, d.dtype_out, d.alpha = L.BF16, (L.BF16 if out == torch.bfloat16 else L.F32), 1.0
     assert "gemv16_kernel" in o.gemm_kernel_symbol(d)
+
+
+# ---- round 3: LayerNorm folded into the Linear next to it (csrc/gemm_rows.hip), decoder row counts --------------------------
+@pytest.mark.parametrize("M,N,H,p,b_km,gelu", [(400, 768, 768, 0.3, False, False), (400, 3072, 768, 0.25, False, True),
+                                               (250, 2304, 768, 0.0, False, False), (77, 648, 128, 0.3, False, False),
+                                               (400, 768, 768, 0.3, True, False)])
+def test_layernorm_folded_into_the_next_linear_forward(M, N, H, p, b_km, gelu):
+    """gstvd_gemm_ln_fwd == gstvd_ln_fwd followed by gstvd_gemm: the normalised rows / mean / rstd it writes are BIT-identical to
+    the stand-alone LayerNorm kernel's (same arithmetic in the same order), the product equals the two-launch result (same bf16
+    operands, same fp32 accumulation order) and the torch fp32 reference within the bf16 bar; ragged M / N tiles, dropout on the
+    LayerNorm's input, GELU (+ saved derivative) epilogue, k-major B."""
+    o = ops()
+    bf = torch.bfloat16
+    x, res = rnd(M, H, dtype=bf, seed=70), rnd(M, H, dtype=bf, seed=71)
+    gamma, beta = 1 + 0.1 * rnd(H, seed=72), 0.1 * rnd(H, seed=73)
+    w = rnd(N, H, dtype=bf, seed=74, s=0.1)
+    wk = w.t().contiguous() if b_km else w
+    bias = rnd(N, seed=75)
+    rng = o.Rng(DEV, seed=5)
+
+    def mk():
+        return dict(mode=o.LN_RESID, dtype=o.BF16, M=M, H=H, gamma=gamma, beta=beta, mean=torch.empty(M, device=DEV),
+                    rstd=torch.empty(M, device=DEV), eps=1e-12, x=x, res=res, y=torch.empty(M, H, device=DEV, dtype=bf),
+                    p_pre=p, site_pre=9, rng=rng)
+    k1, k2 = mk(), mk()
+    epi = o.EPI_GELU if gelu else 0
+    c1, c2 = torch.zeros(M, N, device=DEV, dtype=bf), torch.zeros(M, N, device=DEV, dtype=bf)
+    u1 = torch.zeros(M, N, device=DEV, dtype=bf) if gelu else None
+    u2 = torch.zeros(M, N, device=DEV, dtype=bf) if gelu else None
+    o.ln_fwd(**k1)
+    o.gemm(k1["y"], wk, c1, M, N, H, b_km=b_km, bias=bias, aux=u1, epi=epi)
+    # (gemm_ln_ok is the ENGINE's policy -- shapes whose grid is a single round of the chip; the kernel itself takes all of these)
+    assert o.gemm_ln_ok(M, N, H, bf) == (((M + 15) // 16) * ((N + 127) // 128) <= 512)
+    o.gemm_ln_fwd(k2, wk, c2, N, b_km=b_km, bias=bias, aux=u2, epi=epi)
+    assert torch.equal(k1["y"], k2["y"]) and torch.equal(k1["mean"], k2["mean"])
+    # (H = 768, the decoder's width, runs the same three-vector code as ln_fwd's instantiation: bit-equal; narrower rows take
+    # another instantiation there, whose fused-multiply-add contraction may differ in the last bit of the variance)
+    assert torch.equal(k1["rstd"], k2["rstd"]) if H == 768 else torch.allclose(k1["rstd"], k2["rstd"], rtol=1e-6, atol=0)
+    assert torch.equal(c1, c2)
+    if gelu:
+        assert torch.equal(u1, u2)
+    mask = o.dropout_mask(M * H, p, 9, rng, DEV).view(M, H) if p > 0 else torch.ones(M, H, device=DEV)
+    yref = ln_ref(x.float() * mask + res.float(), gamma, beta).to(bf).float()
+    ref = yref @ w.float().t() + bias
+    check("gemm_ln_fwd", c2, torch.nn.functional.gelu(ref) if gelu else ref, bf, 2.0)
+
+
+@pytest.mark.parametrize("M,N,H,p,dgelu,add", [(400, 768, 768, 0.3, False, True), (400, 3072, 768, 0.25, True, False),
+                                               (250, 768, 768, 0.0, False, False), (77, 648, 128, 0.3, False, True)])
+def test_layernorm_backward_folded_into_the_producers_input_gradient(M, N, H, p, dgelu, add):
+    """gstvd_gemm_ln_bwd == gstvd_ln_bwd followed by the input-gradient GEMM of the Linear that produced the LayerNorm's input
+    (C = dx . W, W row-major [H, N] = k-major B): dres / dx bit-identical to the stand-alone kernel, the product equal to the
+    two-launch result, the column partials (16-row blocks of two rows per wave instead of 4-row blocks) equal after reduction up to fp32
+    reassociation; residual-gradient accumulate and the x gelu' epilogue of the FFN's input gradient."""
+    o = ops()
+    bf = torch.bfloat16
+    x, res = rnd(M, H, dtype=bf, seed=80), rnd(M, H, dtype=bf, seed=81)
+    gamma, beta = 1 + 0.1 * rnd(H, seed=82), 0.1 * rnd(H, seed=83)
+    dy = rnd(M, H, dtype=bf, seed=84)
+    w = rnd(H, N, dtype=bf, seed=85, s=0.1)                    # the producer Linear's weight [out = H, in = N]
+    rng = o.Rng(DEV, seed=6)
+    kw = dict(mode=o.LN_RESID, dtype=o.BF16, M=M, H=H, gamma=gamma, beta=beta, mean=torch.empty(M, device=DEV),
+              rstd=torch.empty(M, device=DEV), eps=1e-12, x=x, res=res, y=torch.empty(M, H, device=DEV, dtype=bf),
+              p_pre=p, site_pre=4, rng=rng)
+    o.ln_fwd(**kw)
+    addend = rnd(M, N, dtype=bf, seed=86) if add else None
+    aux = (rnd(M, N, dtype=bf, seed=87) * 0.5 + 0.5) if dgelu else None
+    epi = o.EPI_DGELU if dgelu else 0
+    # two launches
+    nb1 = o.ln_bwd_blocks(M)
+    p1 = torch.empty(nb1, 3, H, device=DEV)
+    dres1 = torch.empty(M, H, device=DEV, dtype=bf)
+    dx1 = torch.empty(M, H, device=DEV, dtype=bf) if p > 0 else dres1
+    o.ln_bwd(kw, dy, p1, dres=dres1, dx=dx1)
+    c1 = torch.zeros(M, N, device=DEV, dtype=bf)
+    o.gemm(dx1, w, c1, M, N, H, b_km=True, addend=addend, aux=aux, epi=epi)
+    # one launch
+    R = o.gemm_ln_rows()
+    nb2 = (M + R - 1) // R
+    p2 = torch.empty(nb2, 3, H, device=DEV)
+    dres2 = torch.empty(M, H, device=DEV, dtype=bf)
+    dx2 = torch.empty(M, H, device=DEV, dtype=bf) if p > 0 else dres2
+    c2 = torch.zeros(M, N, device=DEV, dtype=bf)
+    o.gemm_ln_bwd(kw, dy, p2, nb2, w, c2, N, dres=dres2, dx=dx2, addend=addend, aux=aux, epi=epi)
+    assert torch.equal(dres1, dres2) and torch.equal(dx1, dx2)
+    assert torch.equal(c1, c2)
+    outs = []
+    for part, nb in ((p1, nb1), (p2, nb2)):
+        dg, db, dbias = torch.empty(H, device=DEV), torch.empty(H, device=DEV), torch.empty(H, device=DEV)
+        o.colsum_partials(part, nb, 3, H, dg, db, dbias, accumulate=False)
+        outs.append((dg, db, dbias))
+    for a, b, name in zip(outs[0], outs[1], ("dgamma", "dbeta", "dbias")):
+        assert (a - b).abs().max().item() <= 1e-4 * max(1.0, a.abs().max().item()), name

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Copy what tools/final_profiles.sh (+ the soak / repro runs) left under gpurun_out/ into profiles/<round>_* (tracked).
-usage: collect_profiles.py r02"""
+usage: collect_profiles.py r03"""
 import os, shutil, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,7 +11,10 @@ names = {"bench_n1.json": "bench_n1.json", "breakdown_events.json": "breakdown_e
          "h2d_probe.txt": "h2d_probe.txt", "eval_decode.json": "eval_decode.json", "gpu_tests_full.log": "gpu_tests_full.log",
          "bench_force_dist_rows16.json": "bench_force_dist_rows16.json", "bench_force_dist_rows10.json": "bench_force_dist_rows10.json",
          "bench_n1_rows10.json": "bench_n1_rows10.json", "decode_attention_kernels.txt": "decode_attention_kernels.txt",
-         "slice_sweep.txt": "slice_sweep.txt", "dist_slice_sweep.txt": "dist_slice_sweep.txt"}
+         "slice_sweep.txt": "slice_sweep.txt", "dist_slice_sweep.txt": "dist_slice_sweep.txt",
+         "slice_defaults_check.txt": "slice_defaults_check.txt", "gemm_vs_vendor_blas.txt": "gemm_vs_vendor_blas.txt",
+         "row_split_probe.txt": "row_split_probe.txt", "grid_barrier.txt": "grid_barrier.txt",
+         "kernel_trace_steps.csv.gz": "kernel_trace_steps.csv.gz"}
 for a, b in names.items():
     p = os.path.join(src, a)
     if os.path.exists(p):

@@ -17,14 +17,16 @@ bash tools/prof_serial.sh > $out/prof_serial.log 2>&1; cp gpurun_out/prof_serial
 bash tools/pmc_bench.sh > $out/pmc.log 2>&1; cp gpurun_out/pmc3/summary.json $out/pmc_traffic.json; rm -rf gpurun_out/pmc3
 # 6. MFMA pipe utilisation of the step's GEMM shapes incl. the connection-layer ones
 bash tools/pmc_mfma.sh > $out/pmc_mfma.log 2>&1; cp gpurun_out/pmc_mfma/summary.json $out/pmc_mfma_util.json
-# 7. timeline of a replayed step
-bash tools/timeline.sh > $out/timeline.txt 2>&1
+# 7. timeline of a STEADY-STATE replayed step (round 3: the median of the replays that are followed by another replay; round 2's
+#    tools/timeline.sh reported the last step of the burst, which has 0.6-0.9 ms of idle time the others do not have)
+bash tools/trace_step.sh > $out/timeline.txt 2>&1; cp gpurun_out/trace/kernel_trace.csv.gz $out/kernel_trace_steps.csv.gz
 # 8. GEMM K-loop study: K slope + ablations + in-kernel clock (diagnostic builds, env-selected)
 ( for ab in 0 1 7 2; do GSTVD_DIAG_ABLATE=$ab python3 tools/clock_probe.py 3072; done
   for ab in 0 1 2 6; do GSTVD_GEMM256_NIU=4 GSTVD_DIAG_ABLATE=$ab python3 tools/kslope.py nt 4096 4096 | sed "s/^/ABLATE=$ab /"; done
   for st in 0 4; do GSTVD_GEMM256_NIU=4 GSTVD_GEMM_ST=$st python3 tools/kslope.py nt 4096 4096 | sed "s/^/ST=$st /"; done
   python3 tools/kslope.py nt 4096 768 64; python3 tools/kslope.py nn 4096 768 64
   python3 tools/gemm_bench.py all; python3 tools/write_floor.py ) > $out/gemm_study.txt 2>/dev/null
+rm -f gst_visdial_amd/lib/libgstvd_hip_diag.so      # (built by the probes above through tools/diag_lib.py; never shipped)
 # 9. host input path next to the replayed step
 ( for m in pinned_async pinned pageable; do python3 tools/h2d_probe.py --mode=$m | tail -5; done ) > $out/h2d_probe.txt 2>/dev/null
 # 10. eval / decode side measurements
@@ -33,9 +35,18 @@ python3 tools/eval_decode_bench.py > $out/eval_decode.json 2> /dev/null
 #      attention kernels at the step's six shapes
 rocprofv3 --kernel-trace --output-format csv -d $out/dec_trace -- python3 tools/decode_debug.py > /dev/null 2>&1
 ( python3 tools/decode_timeline.py $out/dec_trace; python3 tools/sample_probe.py 2>/dev/null | grep top_k; bash tools/attn_shapes.sh 2>/dev/null | grep "^attn" ) > $out/decode_attention_kernels.txt 2>&1; rm -rf $out/dec_trace
-# 10c. N = 1 sweep of the backward pipeline's slice sizes, with / without a separate AdamW stream
-bash tools/slice_sweep.sh > /dev/null 2>&1; cp gpurun_out/r2/slice_sweep.txt $out/slice_sweep.txt
-bash tools/dist_slice_sweep.sh > /dev/null 2>&1; cp gpurun_out/r2/dist_slice_sweep.txt $out/dist_slice_sweep.txt
+# 10c. (round 3) sweeps that chose the backward pipeline's slice lists are kept as profiles/r03_chunk_sweep.txt (tools/chunk_sweep.sh);
+#      here: the defaults against round 2's lists, N = 1 and the 1-rank RCCL path
+rm -f gpurun_out/chunk_sweep.txt
+tools/chunk_sweep.sh "22,27,27,27,27,192" "192" > /dev/null 2>&1
+GSTVD_PIPE_UPDATE_STREAM=0 tools/chunk_sweep.sh "192" > /dev/null 2>&1
+GSTVD_FORCE_DIST=1 tools/chunk_sweep.sh "22,27,27,27,27,96,96,32,16" "128,96,96,32,16" > /dev/null 2>&1
+cp gpurun_out/chunk_sweep.txt $out/slice_defaults_check.txt
+# 10d. evidence behind the round-3 decisions: vendor-BLAS reference timings + K slopes, row scaling of the decoder's kernels,
+#      cost of an in-kernel grid barrier (tools/attic/gridbar.hip.txt, built to build/gridbar by the caller)
+( python3 tools/gemm_bench.py all lib; python3 tools/nt_study.py ) 2>/dev/null | grep -v amdgpu > $out/gemm_vs_vendor_blas.txt
+bash tools/row_split_probe.sh > $out/row_split_probe.txt 2>&1
+[ -x build/gridbar ] && timeout 60 build/gridbar > $out/grid_barrier.txt 2>&1
 cut -c1-400 $out/bench_n1.json; tail -3 $out/gpu_tests_full.log; head -6 $out/kernel_stats_bench.csv | cut -c1-150
 # 11. the N>1 code path on one GPU (1-rank RCCL group: collectives, graded slices, bf16 payload, graph capture), both row counts
 for rows in 16 10; do GSTVD_FORCE_DIST=1 python3 bench.py --steps 10 --warmup 2 --rows-per-gpu $rows --grad-compress bf16 --no-cpu-baseline --no-breakdown --no-fp32 --no-h2d 2>/dev/null | tail -1 > $out/bench_force_dist_rows$rows.json; done

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Back-to-back timing + correctness of the step's main GEMM shapes through the C ABI (bf16 in/out; tn: fp32 out).
-usage: gemm_bench.py [set] [lib]   set in: main (default) | small | all.  Tuning env vars (GSTVD_GEMM_*) apply.
+usage: gemm_bench.py [set] [lib]   set in: main (default) | small | mscale | all.  Tuning env vars (GSTVD_GEMM_*) apply.
 `lib`: also time torch.matmul (the vendor BLAS behind it) on the same operands -- a speed-of-light REFERENCE for the tile design,
 never a code path of the product (which has no BLAS call)."""
 import os, sys
@@ -45,6 +45,10 @@ def run(lay, M, N, K, reps=30):
         lib = "   | vendor BLAS (torch.matmul, bf16 out) %7.1f us %6.1f TFLOP/s" % (ul, 2.0 * M * N * K / ul / 1e6)
     print("%s %5dx%5dx%5d %-22s %7.1f us  %6.1f TFLOP/s  relerr %.1e%s%s" % (lay, M, N, K, ops.gemm_tag(1, a_km, b_km, M, N, 1), us,
           2.0 * M * N * K / us / 1e6, err, "  <-- WRONG" if err > 2e-2 else "", lib))
+# row scaling of the latency-bound decoder / vision problems: would running the decoder's rows as two half-size chains on two
+# streams shorten it?  Only if a launch gets faster with fewer rows.
+MSCALE = [(lay, M, N, K) for (lay, N, K) in (("nt", 768, 768), ("nn", 768, 768), ("nt", 2304, 768), ("nt", 3072, 768), ("nn", 768, 3072))
+          for M in (400, 200, 100)]
 which = sys.argv[1] if len(sys.argv) > 1 else "main"
-for sh in (MAIN if which == "main" else SMALL if which == "small" else MAIN + SMALL):
+for sh in (MAIN if which == "main" else SMALL if which == "small" else MSCALE if which == "mscale" else MAIN + SMALL):
     run(*sh)

@@ -28,6 +28,9 @@ def run(M, H, p, reps=40):
     tb = t(lambda: ops.ln_bwd(kw, dy, partial, dres=dres, dx=dx))
     byt_f, byt_b = 3 * M * H * 2, (5 * M * H * 2 + nblk * 3 * H * 4)
     print("M=%5d H=%4d p=%.1f  fwd %6.1f us (%5.0f GB/s)   bwd %6.1f us (%5.0f GB/s)" % (M, H, p, tf, byt_f / tf / 1e3, tb, byt_b / tb / 1e3))
-for M, H in ((4096, 768), (592, 1024), (400, 768), (16384, 768)):
+shapes = ((4096, 768), (592, 1024), (400, 768), (16384, 768))
+if len(sys.argv) > 1 and sys.argv[1] == "mscale":      # row scaling of the decoder's LayerNorms (see tools/row_split_probe.sh)
+    shapes = ((400, 768), (200, 768), (100, 768))
+for M, H in shapes:
     for p in (0.0, 0.3):
         run(M, H, p)
