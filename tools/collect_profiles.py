@@ -11,7 +11,6 @@ names = {"bench_n1.json": "bench_n1.json", "breakdown_events.json": "breakdown_e
          "h2d_probe.txt": "h2d_probe.txt", "eval_decode.json": "eval_decode.json", "gpu_tests_full.log": "gpu_tests_full.log",
          "bench_force_dist_rows16.json": "bench_force_dist_rows16.json", "bench_force_dist_rows10.json": "bench_force_dist_rows10.json",
          "bench_n1_rows10.json": "bench_n1_rows10.json", "decode_attention_kernels.txt": "decode_attention_kernels.txt",
-         "slice_sweep.txt": "slice_sweep.txt", "dist_slice_sweep.txt": "dist_slice_sweep.txt",
          "slice_defaults_check.txt": "slice_defaults_check.txt", "gemm_vs_vendor_blas.txt": "gemm_vs_vendor_blas.txt",
          "row_split_probe.txt": "row_split_probe.txt", "grid_barrier.txt": "grid_barrier.txt",
          "kernel_trace_steps.csv.gz": "kernel_trace_steps.csv.gz"}
