@@ -1,20 +1,3 @@
-// SHELVED EXPERIMENT (round 3) -- kept as text under tools/attic, not part of the build.
-//
-// Result.  256 x 192 tile on four waves (128 x 96 per wave), accumulators pinned in AGPRs by asm-only MFMAs (no compiler copies:
-// 0 v_accvgpr moves, 0 spills, 88 VGPRs + 192 AGPRs), K-step hand-scheduled in eight regions, split A / B rings (152 KB), correct
-// results.  K-slope at 4096 x 3072 (tools/nt_study.py, GSTVD_GEMM_W4=1):
-//     full loop 0.89 us per 32-deep step | no LDS-DMA in the loop 0.486 | no fragment reads 0.776 | MFMAs only 0.401 (= 48 MFMAs x 16
-//     cycles at the 1.9 GHz the chip holds under MFMA load)        [8-wave kernels of the product: 0.70-0.76; vendor BLAS: 0.49]
-// i.e. MFMA + LDS reads + barrier already run at the vendor's speed; the LDS-DMA ring adds 0.40 us.  With four stages in flight the
-// step time is (L2 -> LDS latency under load, ~3.3 us) / 4 for this kernel AND for the 8-wave kernels (4 x 0.70-0.76 = 2.8-3.0 us):
-// the K loop of every LDS-DMA ring GEMM here is bound by BYTES IN FLIGHT (LDS capacity: 112-128 KB per CU -> 35-42 GB/s per CU at
-// that latency), not by MFMA issue, the LDS port or the schedule.  Going faster needs more bytes in flight than LDS can hold --
-// i.e. staging part of the operands through the ~160 free VGPRs per lane of a four-wave kernel (global_load -> registers ->
-// ds_write), which is presumably what the vendor kernels do.  That hybrid is the open item; this file is its starting point.
-// To build it again: add gemm_w4.hip to csrc/Makefile, `gemm_w4_dispatch` to gemm_common.h and the GSTVD_GEMM_W4 hook in
-// gemm_dma256_dispatch, LPR = 16 for NI > 4 and an AGPR parking variant (asm ds_write_b128 with an "a" operand) in
-// gemm_epilogue_rows -- all in the git history of round 3 (commit "4-wave tile: diagnosis").
-//
 // 256x256x32 bf16 MFMA tile on FOUR waves (each 128x128 = 64 accumulator tiles, 256 accumulator registers), LDS-DMA ring.
 //
 // Why a second 256-tile kernel (round 3).  The 8-wave tile of gemm_dma256.hip (each wave 128x64) reads per 32-deep K-step and
