@@ -139,23 +139,12 @@ DEVFN void st8(bf16* q, const f32x4& lo, const f32x4& hi) {
   *(bf16x8*)q = v;
 }
 
-// AGPR_ACC (gemm_w4.hip): the accumulator tiles live in AGPRs and are only ever touched by inline asm (see mfma_acc there), so
-// they are parked with an asm ds_write_b128 that takes an AGPR data operand; the compiler's waitcnt pass does not see that
-// store, hence the explicit lgkmcnt(0) before the read-back.
-template <bool AGPR_ACC> DEVFN void epi_park_tile(float* dst, const f32x4& v) {
-  if constexpr (AGPR_ACC) {
-    asm volatile("ds_write_b128 %0, %1" ::"v"((unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(const char*)dst), "a"(v) : "memory");
-  } else {
-    *(f32x4*)dst = v;
-  }
-}
-
-template <int MI, int NI, int HB, bool AGPR_ACC = false>
+template <int MI, int NI, int HB>
 DEVFN void gemm_epilogue_rows(const GemmP& p, const DropKey& dk, const f32x4 (&acc)[MI][NI], int64_t z, int64_t mw, int64_t nw,
                               char* lds_wave, int lane) {
   static_assert(MI % HB == 0, "row blocks per pass must divide the wave tile");
   // lanes per row: 8 columns each, rounded up to a power of two (NI = 3: 8 lanes, the last two idle)
-  constexpr int S = epi_row_floats<NI>(), LPR = NI <= 1 ? 2 : (NI <= 2 ? 4 : (NI <= 4 ? 8 : 16)), RPI = 64 / LPR, ROWS = HB * 16;
+  constexpr int S = epi_row_floats<NI>(), LPR = NI <= 1 ? 2 : (NI <= 2 ? 4 : 8), RPI = 64 / LPR, ROWS = HB * 16;
   const int g = lane >> 4, li = lane & 15;
   const int rl = lane / LPR, c8 = (lane % LPR) * 8;
   float* park = (float*)lds_wave;
@@ -193,8 +182,7 @@ DEVFN void gemm_epilogue_rows(const GemmP& p, const DropKey& dk, const f32x4 (&a
 #pragma unroll
     for (int i = 0; i < HB; ++i)
 #pragma unroll
-      for (int j = 0; j < NI; ++j) epi_park_tile<AGPR_ACC>(park + (i * 16 + li) * S + j * 16 + 4 * g, acc[pb * HB + i][j]);
-    if constexpr (AGPR_ACC) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      for (int j = 0; j < NI; ++j) *(f32x4*)(park + (i * 16 + li) * S + j * 16 + 4 * g) = acc[pb * HB + i][j];
 #pragma unroll
     for (int rr = 0; rr < ROWS / RPI; ++rr) {
       const int row = rr * RPI + rl;
@@ -262,8 +250,6 @@ int gemv16_ln_dispatch(const GemmP& p, int64_t batch, int akm, int bkm, int out_
                        void* y_out, int64_t ldy, hipStream_t s);
 // gemm_dma256.hip: 256x256x32 tile for problems whose grid still fills the chip
 int gemm_dma256_dispatch(const GemmP& p, int64_t batch, int akm, int bkm, int out_f32, hipStream_t s);
-// gemm_w4.hip: the same tile on four waves of 128x128 (niu: 4 = 256-wide, 3 = 192-wide)
-int gemm_w4_dispatch(const GemmP& p, int64_t batch, int akm, int bkm, int out_f32, int niu, hipStream_t s);
 
 // LDS-DMA issue in inline asm.  The compiler's waitcnt pass treats a *builtin* global_load_lds as a pending LDS write and
 // puts `s_waitcnt vmcnt(0)` in front of every ds_read_b64_tr_b16 that follows (it cannot see that the ring slot being

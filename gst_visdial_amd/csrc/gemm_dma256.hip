@@ -612,8 +612,6 @@ int gemm_dma256_dispatch(const GemmP& p, int64_t batch, int akm, int bkm, int ou
   const int64_t tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256) * batch;
   if (p.M < 256 || p.N < 256 || tiles < min_tiles) return GSTVD_E_UNSUPPORTED;
   const int niu = pick_niu(p, batch);
-  static const int w4 = [] { const char* e = getenv("GSTVD_GEMM_W4"); return e ? atoi(e) : 0; }();
-  if (w4) { const int rc = gemm_w4_dispatch(p, batch, akm, bkm, out_f32, niu, s); if (rc != GSTVD_E_UNSUPPORTED) return rc; }
   return out_f32 ? launch256_layout<float>(p, batch, akm, bkm, niu, s) : launch256_layout<bf16>(p, batch, akm, bkm, niu, s);
 }
 
