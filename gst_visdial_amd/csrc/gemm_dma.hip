@@ -233,8 +233,17 @@ static int dma_layout(const GemmP& p, int64_t batch, hipStream_t s) {
     const int64_t ntm = (p.M + 127) / 128, t128 = ntm * ((p.N + 127) / 128) * batch, t96 = ntm * ((p.N + 95) / 96) * batch;
     const double nkt = (double)((p.K + 63) / 64);
     const double c128 = (double)((t128 + 255) / 256) * (8.0 + 0.45 * nkt), c96 = (double)((t96 + 255) / 256) * (8.0 + 0.40 * nkt);
-    if (n96 == 2 || (n96 == 1 && c96 < c128)) return dma_launch<OT, 128, 128, 4, 2, AKM, BKM, 5, 3>(p, batch, s);
-    return dma_launch<OT, 128, 128, 2, 4, AKM, BKM, 5>(p, batch, s);
+    // Ring depth 3 (96 KB), not 5 (160 KB = the whole LDS of a CU): the K-step rate is the same (0.52-0.65 against
+    // 0.56-0.62 us per 64-deep step -- the loop is bound by the L2 -> LDS feed rate, not by the bytes in flight), and the
+    // 64 KB left free let a workgroup of another stream's kernel share the CU: 1174-1178 against 1167-1172 rounds/s in
+    // the step (round 3).  GSTVD_GEMM128_NS=5 keeps the deep ring for A/B.
+    static const int ns128 = [] { const char* e = getenv("GSTVD_GEMM128_NS"); return e ? atoi(e) : 3; }();
+    if (n96 == 2 || (n96 == 1 && c96 < c128)) {
+      if (ns128 == 5) return dma_launch<OT, 128, 128, 4, 2, AKM, BKM, 5, 3>(p, batch, s);
+      return dma_launch<OT, 128, 128, 4, 2, AKM, BKM, 3, 3>(p, batch, s);
+    }
+    if (ns128 == 5) return dma_launch<OT, 128, 128, 2, 4, AKM, BKM, 5>(p, batch, s);
+    return dma_launch<OT, 128, 128, 2, 4, AKM, BKM, 3>(p, batch, s);
   }
   if (variant == 3) return dma_launch<OT, 64, 64, 2, 2, AKM, BKM, 4>(p, batch, s);
   // (32x32 / 32x64 tiles for the skinny M = 400 / 592 problems were measured in round 2: no faster -- 400x768x768 9.8-11.0 us
@@ -242,6 +251,7 @@ static int dma_layout(const GemmP& p, int64_t batch, hipStream_t s) {
   // bytes in flight per ~2 us round trip, so halving the tile halves the bytes in flight along with the bytes needed.
   // 64x32 tiles -- half the weight bytes per workgroup, twice the workgroups: 8.7-8.8 us against 9.1-9.5 us at M = 400, 18 us
   // against 13 us at M = 592.  Not adopted.)
+  // (ring depth 8 / 6 / 5 / 4 measured inside the step in round 3: 1198 / 1202 / 1201 / 1200 rounds/s, i.e. no difference)
   return dma_launch<OT, 64, 64, 2, 2, AKM, BKM, 8>(p, batch, s);
 }
 

@@ -14,7 +14,12 @@
 
 static __device__ __attribute__((aligned(256))) char g_zero_page256[256];
 static constexpr int g_strip_w = 8;      // column-strip width of the tile order (measured 2 / 4 / 8: 31.3 / 30.7 / 30.5 us at 4096x3072x768)
-constexpr int NS256 = 5;    // ring depth: 5 x 32 KB = the whole 160 KB LDS of a CU
+// Ring depth.  Rounds 1-2 used 5 stages (the whole 160 KB LDS of a CU).  Round 3 measured the K-step slope at 5 / 4 / 3 stages
+// (tools/nt_study.py on three builds): 0.669 / 0.686 / 0.684 us (producer / consumer form), 0.775 / 0.736 / 0.778 us (8-wave form)
+// -- the K loop is bound by the RATE at which a CU takes operands in, not by bytes in flight -- while every stage less takes
+// ~0.8 us off the fill in front of the first MFMA: 29.0 -> 27.8 us at 4096x3072x768, step +0.8 % (1190 vs 1181 rounds/s, three
+// A/B pairs).  The LDS allocation is the larger of the ring and the epilogue's parking space.
+constexpr int NS256 = 3;
 // Timing ablations and in-kernel clock stamps exist only in the DIAGNOSTIC build of this file (-DGSTVD_DIAG ->
 // lib/libgstvd_hip_diag.so, `make diag`; loaded by tools/ only, never by gst_visdial_amd/_lib.py): several of them compute
 // wrong results on purpose, and no environment variable may be able to make the product library do that.
@@ -523,7 +528,9 @@ __global__ __launch_bounds__(512) void gemm_dma256_grouped_kernel(const gstvd_ge
   dma_tile256<OT, AKM, BKM, PF, 4, ST>(p, 0, gid - tile_off[lo], ntn, ntm * ntn, smem);
 }
 
-constexpr int LDS256 = NS256 * (256 + 256) * 64;           // the ring is the whole LDS of a CU
+constexpr int RING256 = NS256 * (256 + 256) * 64;
+constexpr int PARK256 = 8 * epi_wave_bytes<4, 4>();        // eight waves park 4 x 4 accumulator tiles each (row-wise epilogue)
+constexpr int LDS256 = RING256 > PARK256 ? RING256 : PARK256;
 
 template <typename OT, bool AKM, bool BKM>
 static int launch256(const GemmP& p, int64_t batch, int niu, hipStream_t s) {
