@@ -259,42 +259,45 @@ DEVFN void attn_fwd_body(const gstvd_attn_t& a, char* smem) {
 #pragma unroll
   for (int i = 0; i < D / 16; ++i) accO[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // chunk c+1's K / V / mask loads are issued right after chunk c has been parked in LDS and fly during its compute
-  Stage64<T, D> pk, pv;
-  float pm = -INFINITY;
-  auto prefetch = [&](int c0) {
-    pk.load(Kb, a.ldk, c0, a.Lk, tid);
-    pv.load(Vb, a.ldv, c0, a.Lk, tid);
+  // The K / V / mask loads of a chunk are issued PF chunks ahead of its use (PF register stages).  PF = 2 was measured in
+  // round 3 (d = 64, 154 registers): 18.1 us against 17.1 us for the text shape, 10.6 against 10.5 us for the cross-attention
+  // shape -- the kernel is not waiting for these loads; one stage it stays.
+  constexpr int PF = 1;
+  struct Stage { Stage64<T, D> k, v; float m; };
+  Stage st[PF];
+  auto prefetch = [&](Stage& sg, int c0) {
+    sg.k.load(Kb, a.ldk, c0, a.Lk, tid);
+    sg.v.load(Vb, a.ldv, c0, a.Lk, tid);
     if (tid < 64) {      // additive mask term of the key: 0 (valid), mask_neg (masked out), -inf (past the end)
       const int key = c0 + tid;
-      pm = -INFINITY;
-      if (key < a.Lk) pm = (a.key_mask == nullptr || a.key_mask[(int64_t)bk * a.Lk + key] != 0.f) ? 0.f : a.mask_neg;
+      sg.m = -INFINITY;
+      if (key < a.Lk) sg.m = (a.key_mask == nullptr || a.key_mask[(int64_t)bk * a.Lk + key] != 0.f) ? 0.f : a.mask_neg;
     }
   };
-  prefetch(0);
-  for (int c0 = 0; c0 < a.Lk; c0 += 64) {
+  auto chunk = [&](Stage& sg, const int c0) {
     __syncthreads();
-    pk.store(sK, nullptr, tid);
-    pv.store(Img<T, D>::BF ? nullptr : sV, Img<T, D>::BF ? sV : nullptr, tid);
-    if (tid < 64) smask[tid] = pm;
+    sg.k.store(sK, nullptr, tid);
+    sg.v.store(Img<T, D>::BF ? nullptr : sV, Img<T, D>::BF ? sV : nullptr, tid);
+    if (tid < 64) smask[tid] = sg.m;
     __syncthreads();
-    if (c0 + 64 < a.Lk) prefetch(c0 + 64);
+    if (c0 + 64 * PF < a.Lk) prefetch(sg, c0 + 64 * PF);
     const int ntile = (a.Lk - c0 + 15) / 16 < 4 ? (a.Lk - c0 + 15) / 16 : 4;
-    // TF tiles per softmax update: the whole chunk for d <= 64, half of it for d = 128 (register budget of two waves per SIMD)
-#pragma unroll 1
-    for (int hf = 0; hf < 4 / TF; ++hf) {
-      const int nt = ntile - TF * hf, k0 = 16 * TF * hf;
-      if (nt <= 0) break;
+    // TF tiles per softmax update: the whole chunk for d <= 64, half of it for d = 128 (register budget of two waves per SIMD).
+    // FULL: all TF tiles present and no causal mask -- the body then has no control flow at all (the generic form tests
+    // `t < nt` around every tile, which the compiler turns into a scalar branch per tile: basic blocks of a few instructions,
+    // nothing for the scheduler to interleave with the MFMAs).
+    auto tiles = [&](auto full_tag, const int nt, const int k0) {
+      constexpr bool FULL = decltype(full_tag)::value;
       f32x4 s[TF];
 #pragma unroll
       for (int t = 0; t < TF; ++t)
-        if (t < nt) s[t] = first_product<T, D>(sK, k0 + t * 16, qf, lane);
+        if (FULL || t < nt) s[t] = first_product<T, D>(sK, k0 + t * 16, qf, lane);
       float val[TF][4], mx = -INFINITY;
 #pragma unroll
       for (int t = 0; t < TF; ++t) {
-        if (t < nt) {
+        if (FULL || t < nt) {
           f32x4 madd = *(const f32x4*)(smask + k0 + t * 16 + 4 * g);
-          if (a.causal) {
+          if (!FULL && a.causal) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
               if (c0 + k0 + t * 16 + 4 * g + r > q && madd[r] == 0.f) madd[r] = a.mask_neg;   // causal x padding: the term is added once
@@ -318,7 +321,7 @@ DEVFN void attn_fwd_body(const gstvd_attn_t& a, char* smem) {
       float pd[TF][4], ps = 0.f;
 #pragma unroll
       for (int t = 0; t < TF; ++t) {
-        if (t < nt) {
+        if (FULL || t < nt) {
           const f32x4 fac = drop_factor4e<E32>(dk, ebase + (uint64_t)(c0 + k0 + t * 16));
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -331,10 +334,25 @@ DEVFN void attn_fwd_body(const gstvd_attn_t& a, char* smem) {
       l_part += ps;
 #pragma unroll
       for (int pr = 0; pr < TF / 2; ++pr) {
-        if (2 * pr + 1 < nt) second_product_pair<T, D>(accO, sV, k0 + 32 * pr, pd[2 * pr], pd[2 * pr + 1], lane);
+        if (FULL || 2 * pr + 1 < nt) second_product_pair<T, D>(accO, sV, k0 + 32 * pr, pd[2 * pr], pd[2 * pr + 1], lane);
         else if (2 * pr < nt) second_product<T, D>(accO, sV, k0 + 32 * pr, pd[2 * pr], lane);
       }
+    };
+#pragma unroll 1
+    for (int hf = 0; hf < 4 / TF; ++hf) {
+      const int nt = ntile - TF * hf, k0 = 16 * TF * hf;
+      if (nt <= 0) break;
+      if (TF == 4 && nt >= TF && !a.causal) tiles(std::true_type{}, TF, k0);
+      else tiles(std::false_type{}, nt, k0);
     }
+  };
+#pragma unroll
+  for (int j = 0; j < PF; ++j)
+    if (64 * j < a.Lk) prefetch(st[j], 64 * j);
+  for (int c0 = 0; c0 < a.Lk; c0 += 64 * PF) {
+#pragma unroll
+    for (int j = 0; j < PF; ++j)
+      if (c0 + 64 * j < a.Lk) chunk(st[j], c0 + 64 * j);
   }
   const float l_tot = rows_sum(l_part);
   const float inv = 1.f / l_tot;
@@ -529,26 +547,25 @@ DEVFN void attn_bwd_dq_body(const gstvd_attn_t& a, const int bx, char* smem) {
     // per-tile bookkeeping, few enough live values for three waves per SIMD (a whole chunk at once needed 296 registers in the
     // merged kernel: one wave per SIMD, 105 us instead of 61 for the text shape).  d = 128: one -- the accumulators, operand
     // fragments and prefetch registers of that width leave no room for a second tile at two waves per SIMD.
-#pragma unroll 1
-    for (int pr = 0; pr < 4 / TP; ++pr) {
-      const int nt = ntile - TP * pr;
-      if (nt <= 0) break;
+    // FULL: all TP tiles present, no causal mask -- a body without control flow (see attn_fwd_body)
+    auto tiles = [&](auto full_tag, const int pr, const int nt) {
+      constexpr bool FULL = decltype(full_tag)::value;
       f32x4 s[TP], dp[TP];
       float ds[TP][4];
 #pragma unroll
       for (int tt = 0; tt < TP; ++tt) {
-        if (tt < nt) {
+        if (FULL || tt < nt) {
           s[tt] = first_product<T, D>(sKr, 16 * TP * pr + tt * 16, qf, lane);
           dp[tt] = first_product<T, D>(sVr, 16 * TP * pr + tt * 16, dof, lane);
         }
       }
 #pragma unroll
       for (int tt = 0; tt < TP; ++tt) {
-        if (tt < nt) {
+        if (FULL || tt < nt) {
           const int k0 = 16 * TP * pr + tt * 16;
           const f32x4 fac = drop_factor4e<E32>(dk, ebase + (uint64_t)(c0 + k0));
           f32x4 madd = *(const f32x4*)(smask + k0 + 4 * g);
-          if (a.causal) {
+          if (!FULL && a.causal) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
               if (c0 + k0 + 4 * g + r > q && madd[r] == 0.f) madd[r] = a.mask_neg;
@@ -560,8 +577,15 @@ DEVFN void attn_bwd_dq_body(const gstvd_attn_t& a, const int bx, char* smem) {
           }
         }
       }
-      if (TP > 1 && nt > 1) second_product_pair<T, D>(acc, sKt, 16 * TP * pr, ds[0], ds[TP - 1], lane);
+      if (TP > 1 && (FULL || nt > 1)) second_product_pair<T, D>(acc, sKt, 16 * TP * pr, ds[0], ds[TP - 1], lane);
       else second_product<T, D>(acc, sKt, 16 * TP * pr, ds[0], lane);
+    };
+#pragma unroll 1
+    for (int pr = 0; pr < 4 / TP; ++pr) {
+      const int nt = ntile - TP * pr;
+      if (nt <= 0) break;
+      if (TP > 1 && nt >= TP && !a.causal) tiles(std::true_type{}, pr, TP);      // (TP = 1: the generic body has no tile tests)
+      else tiles(std::false_type{}, pr, nt);
     }
   }
   if (qv) {
@@ -651,22 +675,20 @@ DEVFN void attn_bwd_dkv_body(const gstvd_attn_t& a, const int bx, char* smem) {
     if (c0 + 64 < a.Lq) prefetch(c0 + 64);
     const int ntile = (a.Lq - c0 + 15) / 16 < 4 ? (a.Lq - c0 + 15) / 16 : 4;
     const uint64_t e2chunk = e2lane + (uint64_t)c0 * half;
-#pragma unroll 1
-    for (int pr = 0; pr < 4 / TP; ++pr) {
-      const int nt = ntile - TP * pr;
-      if (nt <= 0) break;
+    auto tiles = [&](auto full_tag, const int pr, const int nt) {
+      constexpr bool FULL = decltype(full_tag)::value;
       f32x4 s[TP], dp[TP];
       float pd[TP][4], ds[TP][4];
 #pragma unroll
       for (int tt = 0; tt < TP; ++tt) {
-        if (tt < nt) {
+        if (FULL || tt < nt) {
           s[tt] = first_product<T, D>(sQr, 16 * TP * pr + tt * 16, kf, lane);     // [q = 4g+r][key = li]
           dp[tt] = first_product<T, D>(sOr, 16 * TP * pr + tt * 16, vf, lane);
         }
       }
 #pragma unroll
       for (int tt = 0; tt < TP; ++tt) {
-        if (tt < nt) {
+        if (FULL || tt < nt) {
           const int q0 = 16 * TP * pr + tt * 16;
           const f32x4 lse4 = *(const f32x4*)(sLse + q0 + 4 * g);
           const f32x4 del4 = *(const f32x4*)(sDel + q0 + 4 * g);
@@ -687,20 +709,27 @@ DEVFN void attn_bwd_dkv_body(const gstvd_attn_t& a, const int bx, char* smem) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float add = kadd;
-            if (a.causal && key > c0 + q0 + 4 * g + r && add == 0.f) add = a.mask_neg;
+            if (!FULL && a.causal && key > c0 + q0 + 4 * g + r && add == 0.f) add = a.mask_neg;
             const float p = __expf(s[tt][r] * a.scale + add - lse4[r]);
             pd[tt][r] = p * f[r];
             ds[tt][r] = p * (dp[tt][r] * f[r] - del4[r]) * a.scale;
           }
         }
       }
-      if (TP > 1 && nt > 1) {
+      if (TP > 1 && (FULL || nt > 1)) {
         second_product_pair<T, D>(accV, sOt, 16 * TP * pr, pd[0], pd[TP - 1], lane);
         second_product_pair<T, D>(accK, sQt, 16 * TP * pr, ds[0], ds[TP - 1], lane);
       } else {
         second_product<T, D>(accV, sOt, 16 * TP * pr, pd[0], lane);
         second_product<T, D>(accK, sQt, 16 * TP * pr, ds[0], lane);
       }
+    };
+#pragma unroll 1
+    for (int pr = 0; pr < 4 / TP; ++pr) {
+      const int nt = ntile - TP * pr;
+      if (nt <= 0) break;
+      if (TP > 1 && nt >= TP && !a.causal) tiles(std::true_type{}, pr, TP);      // (TP = 1: the generic body has no tile tests)
+      else tiles(std::false_type{}, pr, nt);
     }
   }
   if (kv) {
