@@ -93,7 +93,7 @@ DEVFN float wave_max(float v) {
 // v_mul_lo_u32 issues at quarter rate and the attention kernels, which draw once per two score elements, are VALU bound).
 // The fold in front of each multiply brings bits 16..31 down into the 24 bits the multiply reads.  Avalanche (every output
 // bit flips with probability 0.497-0.503 for every input bit) and the keep statistics of sequential counters match the
-// 32-bit-multiply mixer it replaced (round 3; numpy check in DESIGN.md section 4).
+// 32-bit-multiply mixer it replaced (round 3; numbers in DESIGN.md section 3, "Activations").
 DEVFN uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x = __umul24(x, 0xeb352dU); x ^= x >> 15; x = __umul24(x, 0x6ca68bU); x ^= x >> 16;
   return x;
