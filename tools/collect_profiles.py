@@ -13,7 +13,8 @@ names = {"bench_n1.json": "bench_n1.json", "breakdown_events.json": "breakdown_e
          "bench_n1_rows10.json": "bench_n1_rows10.json", "decode_attention_kernels.txt": "decode_attention_kernels.txt",
          "slice_defaults_check.txt": "slice_defaults_check.txt", "gemm_vs_vendor_blas.txt": "gemm_vs_vendor_blas.txt",
          "row_split_probe.txt": "row_split_probe.txt", "grid_barrier.txt": "grid_barrier.txt",
-         "kernel_trace_steps.csv.gz": "kernel_trace_steps.csv.gz"}
+         "kernel_trace_steps.csv.gz": "kernel_trace_steps.csv.gz", "launch_floor.txt": "launch_floor.txt",
+         "attention_study.txt": "attention_study.txt", "ring_depth_ab.txt": "ring_depth_ab.txt"}
 for a, b in names.items():
     p = os.path.join(src, a)
     if os.path.exists(p):
