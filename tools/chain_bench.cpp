@@ -12,10 +12,10 @@ static void fill(gstvd_gemm_t& g, void* A, void* B, void* C, int64_t M, int64_t 
   g.dtype_in = GSTVD_BF16; g.dtype_out = GSTVD_BF16; g.alpha = 1.f;
 }
 int main(int argc, char** argv) {
-  const int64_t M = argc > 1 ? atoi(argv[1]) : 400, N = 768, K = 768;
+  const int64_t M = argc > 1 ? atoi(argv[1]) : 400, N = 768, K = argc > 3 ? atoi(argv[3]) : 768;
   const int n = argc > 2 ? atoi(argv[2]) : 96;
   void *A, *B, *C0, *C1;
-  hipMalloc(&A, 4096 * K * 2); hipMalloc(&B, N * K * 2); hipMalloc(&C0, 4096 * N * 2); hipMalloc(&C1, 4096 * N * 2);
+  hipMalloc(&A, 4096 * K * 2 + 4096); hipMalloc(&B, N * K * 2 + 4096); hipMalloc(&C0, 4096 * N * 2); hipMalloc(&C1, 4096 * N * 2);
   hipMemset(A, 0, 4096 * K * 2); hipMemset(B, 0, N * K * 2);
   hipStream_t s0, s1; hipStreamCreate(&s0); hipStreamCreate(&s1);
   hipEvent_t e0, e1, ej; hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreateWithFlags(&ej, hipEventDisableTiming);
@@ -44,5 +44,31 @@ int main(int argc, char** argv) {
   };
   printf("M = %ld, %d steps per chain\n", (long)M, n);
   run(0); run(1); run(2);
+  // mode 3 / 4: the mode 0 / mode 1 launches captured into a hipGraph and replayed
+  for (int mode = 3; mode <= 4; ++mode) {
+    hipGraph_t g; hipGraphExec_t ge;
+    hipStreamBeginCapture(s0, hipStreamCaptureModeGlobal);
+    if (mode == 4) { hipEventRecord(ej, s0); hipStreamWaitEvent(s1, ej, 0); }
+    for (int i = 0; i < n; ++i) {
+      if (mode == 3) gstvd_gemm(&gf, s0);
+      else { gstvd_gemm(&gh0, s0); gstvd_gemm(&gh1, s1); }
+    }
+    if (mode == 4) { hipEventRecord(ej, s1); hipStreamWaitEvent(s0, ej, 0); }
+    hipStreamEndCapture(s0, &g);
+    hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    for (int rep = 0; rep < 4; ++rep) {
+      hipDeviceSynchronize();
+      auto t0 = std::chrono::high_resolution_clock::now();
+      hipEventRecord(e0, s0);
+      hipGraphLaunch(ge, s0);
+      hipEventRecord(e1, s0);
+      auto t1 = std::chrono::high_resolution_clock::now();
+      hipDeviceSynchronize();
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      if (rep == 3) printf("  mode %d (hipGraph replay of mode %d): GPU %.1f us total = %.2f us per chain step; host %.1f us\n", mode, mode - 3, ms * 1e3,
+                           ms * 1e3 / n, std::chrono::duration<double, std::micro>(t1 - t0).count());
+    }
+    hipGraphExecDestroy(ge); hipGraphDestroy(g);
+  }
   return 0;
 }
