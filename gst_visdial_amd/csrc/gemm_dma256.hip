@@ -1,4 +1,5 @@
-// 256x256x32 bf16 MFMA GEMM tile, 8 waves (each 128x64), LDS-DMA 5-stage ring (the whole 160 KB LDS of a CU).
+// 256x256x32 bf16 MFMA GEMM tile, 8 waves (each 128x64), LDS-DMA ring of NS256 stages (3 since round 3; 5 = the whole 160 KB LDS
+// of a CU in rounds 1-2).
 //
 // Measured on MI355X (profiles/r01_pmc_gemm_l2_fetch.json): with 128x128x64 tiles the main loop is bound by the rate
 // at which a CU can fill LDS (~35-50 GB/s per CU, L2 hit 70-82 %), i.e. by bytes staged per FLOP (1 B / 64 FLOP).
