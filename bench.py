@@ -6,8 +6,15 @@ already resident in HBM: dropout-on forward + LM cross-entropy + backward + (N>1
 overlapped with backward) + fused AdamW update, bf16 storage / fp32 accumulation.  Nothing is skipped.
 
   python bench.py --gpus 1 --steps 10 --warmup 3
+  python bench.py --gpus N --steps K --warmup W          # N > 1 without RANK/WORLD_SIZE: bench.py starts its own N ranks
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-         bench.py --gpus N --steps K --warmup W
+         bench.py --gpus N --steps K --warmup W          # ... or is started as one of them
+
+`--gpus N` is a promise about the run, not a hint: the line says n_gpus = N and config.rccl.ranks_seen_by_allreduce = N or the
+process exits non-zero.  A plain `python bench.py --gpus N` (no rank environment) is the LAUNCHER: before any GPU call it checks
+that N devices are visible and starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process (never
+an exec), relays rank 0's JSON as its own last line and propagates the exit code (train_gen.py:295,324-329 -- the reference's
+DataParallel wrapping -- is what the N ranks replace).
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline      the dominant kernel (bf16 MFMA GEMM family): algorithmic FLOPs per launch / average launch
@@ -30,6 +37,116 @@ import torch  # noqa: E402
 
 FLOP_PER_ROW_TRAIN = 274.0e9      # useful fwd 91.4 GF + bwd 182.6 GF per dialog round, T=256,R=37,U=25
 PEAK_BF16_TFLOPS = 2500.0         # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0             # HBM3E peak, same guide (6.3 TB/s is what a float4 copy reaches)
+
+
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def parse_last_json(text):
+    """The contract's "last stdout line is the JSON": returns (object or None, the text in front of that line)."""
+    lines = text.rstrip("\n").split("\n")
+    for i in range(len(lines) - 1, -1, -1):
+        ln = lines[i].strip()
+        if not ln:
+            continue
+        if ln.startswith("{") and ln.endswith("}"):
+            try:
+                return json.loads(ln), "\n".join(lines[:i])
+            except ValueError:
+                return None, text
+        return None, text
+    return None, text
+
+
+def check_rank_count(line, n):
+    """None if the JSON line really describes an n-rank run, else the reason it does not."""
+    if not isinstance(line, dict):
+        return "rank 0 printed no JSON line"
+    if line.get("n_gpus") != n:
+        return "the line says n_gpus = %r, asked for %d" % (line.get("n_gpus"), n)
+    rccl = (line.get("config") or {}).get("rccl") or {}
+    if n > 1 and (rccl.get("world_size") != n or rccl.get("ranks_seen_by_allreduce") != n):
+        return ("the communicator spans world_size = %r / ranks_seen_by_allreduce = %r ranks, asked for %d"
+                % (rccl.get("world_size"), rccl.get("ranks_seen_by_allreduce"), n))
+    return None
+
+
+def launch_ranks(n, argv, worker_cmd=None, visible_gpus=None, env=None, timeout=None):
+    """`python bench.py --gpus n` without a rank environment: start the n ranks as a child process group and relay rank 0's line.
+
+    Runs BEFORE anything touches the GPU (torch.cuda.device_count() does not initialise it on this stack; is_available() would)
+    and never replaces this process: `python -m torch.distributed.run` is a child (subprocess), its exit code is returned.
+    Returns (exit code, JSON object or None, relayed stdout in front of the JSON line).
+      worker_cmd     what each rank runs (default: this file); a test passes a stub that needs no GPU
+      visible_gpus   override of the device count (tests)"""
+    import subprocess
+    one_gpu_validation = bool((env or os.environ).get("GSTVD_BENCH_ONE_GPU"))
+    if visible_gpus is None:
+        visible_gpus = torch.cuda.device_count()
+    if visible_gpus < n and not one_gpu_validation:
+        sys.stderr.write("bench: --gpus %d asked for, %d GPU(s) visible on this node: refusing to report a %d-GPU number "
+                         "from fewer devices (run with --gpus %d, or on a node with %d GPUs)\n"
+                         % (n, visible_gpus, n, max(visible_gpus, 1), n))
+        return 4, None, ""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port())]
+    cmd += list(worker_cmd) if worker_cmd else [os.path.abspath(__file__)]
+    cmd += list(argv)
+    cenv = dict(env if env is not None else os.environ)
+    cenv.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this host driver
+    cenv.setdefault("OMP_NUM_THREADS", "8")
+    sys.stderr.write("bench: launching %d ranks: %s\n" % (n, " ".join(cmd)))
+    try:
+        r = subprocess.run(cmd, env=cenv, stdout=subprocess.PIPE, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        sys.stderr.write("bench: the %d-rank run did not finish within %s s\n" % (n, timeout))
+        return 5, None, ""
+    text = r.stdout.decode("utf-8", "replace")
+    line, head = parse_last_json(text)
+    rc = r.returncode
+    if rc == 0:
+        why = check_rank_count(line, n)
+        if why:
+            sys.stderr.write("bench: the %d-rank run is not a valid %d-GPU measurement: %s\n" % (n, n, why))
+            rc = 6
+    else:
+        sys.stderr.write("bench: the %d-rank run exited with code %d\n" % (n, rc))
+    return rc, (line if rc == 0 else None), (head if line is not None else text)
+
+
+def launcher_main(n, argv):
+    rc, line, head = launch_ranks(n, argv)
+    if head.strip():
+        print(head, flush=True)
+    if line is not None:
+        line.setdefault("config", {})["launched_by"] = "bench.py --gpus %d (self-launched %d ranks via torch.distributed.run, child process)" % (n, n)
+        print(json.dumps(line), flush=True)
+    return rc
+
+
+def run_leg(name, extra, base_argv, rank, world, local, port, timeout=420):
+    """One extra measurement beside the headline (a different rows/GPU or gradient payload), each in a FRESH child process per
+    rank (own process group on its own port, own hipGraph capture): a failure there costs that leg, never the headline line.
+    Every rank calls this with the same arguments after the parent's process group is gone; rank 0 returns the leg's JSON."""
+    import subprocess
+    env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local), MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(port))
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(base_argv) + list(extra) + ["--leg", name]
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return {"error": "leg %s: no result within %d s" % (name, timeout)}
+    if rank != 0:
+        return None
+    line, _ = parse_last_json(r.stdout.decode("utf-8", "replace"))
+    if r.returncode != 0 or line is None:
+        return {"error": "leg %s: child exit code %d%s" % (name, r.returncode, "" if line else ", no JSON line")}
+    return line
 
 
 def synthetic_rows(B, T, R, U, F, V, seed, device):
@@ -86,12 +203,15 @@ def build_model(device, precision, seed, streams=True):
 
 
 def cpu_baseline(model, T, R, U, F, V, rows=2):
-    """The oracle (parity-checked port of the reference) on the host cores: forward + loss + backward, fp32."""
+    """The oracle (parity-checked port of the reference) on the host cores: forward + loss + backward, fp32, TRAIN mode.
+
+    BASELINE.md section 4's procedure: model.train() (the oracle's `train=True`: F.dropout on the host RNG at every one of the
+    reference's dropout sites -- 11 % of the reference's own CPU time is bernoulli_), 1 untimed warm-up + 3 timed steps of the
+    same sample, MEDIAN reported, thread count and logical-CPU count printed.  One deviation, stated in the line: the thread count
+    is min(os.cpu_count(), 16), not os.cpu_count() -- eager fp32 PyTorch on the 256-thread GPU-box host collapses with every
+    logical CPU in the pool (measured 900 s for 2 rows with 256 threads)."""
     from gst_visdial_amd.config import bert_base_enc_config, bert_base_dec_config
     from oracle import vd_oracle as O
-    # eager fp32 PyTorch at these sizes stops scaling (and on a 256-thread host collapses: measured 900 s for
-    # 2 rows with 256 threads) well before all cores are busy, so the sample uses at most 16 threads and is
-    # bounded to one row first; a second, 2-row sample is only taken when the first finished quickly.
     threads = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(threads)
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
@@ -101,14 +221,15 @@ def cpu_baseline(model, T, R, U, F, V, rows=2):
     def one(B, Tt):
         b = synthetic_rows(B, Tt, R, U, F, V, 999, "cpu")
         t0 = time.perf_counter()
-        O.grads(sd, enc_cfg, dec_cfg, b, keys, wrt_feats=False)
+        O.grads(sd, enc_cfg, dec_cfg, b, keys, wrt_feats=False, train=True)
         return time.perf_counter() - t0
 
-    one(1, 16)                                     # thread-pool / allocator warm-up (untimed)
-    n, dt = 1, one(1, T)
-    if dt < 8.0:                                   # size the real sample for ~15 s of CPU work (cap 32 rows)
-        n = max(2, min(48, int(22.0 / max(dt, 1e-3))))
-        dt = one(n, T)
+    one(1, 16)                                     # thread-pool / allocator warm-up (tiny, untimed)
+    t1 = one(1, T)                                 # sizing probe: how many rows fit ~5 s per timed step (so 1 + 3 steps stay ~20 s)
+    n = max(1, min(32, int(5.0 / max(t1, 1e-3))))
+    one(n, T)                                      # the procedure's warm-up step (untimed)
+    times = sorted(one(n, T) for _ in range(3))
+    dt = times[1]                                  # median of 3
     cpu_model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
@@ -116,9 +237,66 @@ def cpu_baseline(model, T, R, U, F, V, rows=2):
     except OSError:
         pass
     return {"value": n / dt, "unit": "dialog-rounds/sec", "cores": threads, "kind": "port", "cpu_model": cpu_model,
-            "host_logical_cpus": os.cpu_count(),
-            "sample": "%d row(s) x 1 train step (fwd+loss+bwd, fp32, T=%d R=%d U=%d) of oracle/vd_oracle.py on %d threads; %.1f s"
-                      % (n, T, R, U, threads, dt)}
+            "host_logical_cpus": os.cpu_count(), "mode": "train (dropout on, host RNG)", "timed_steps": 3, "warmup_steps": 1,
+            "step_seconds": [round(t, 2) for t in times],
+            "sample": "%d row(s) x (1 warm-up + 3 timed) train steps (fwd+loss+bwd, fp32, dropout on, T=%d R=%d U=%d) of oracle/vd_oracle.py "
+                      "on %d of %d logical CPUs; median %.1f s per step" % (n, T, R, U, threads, os.cpu_count() or 0, dt)}
+
+
+def eval_decode_side(device, V):
+    """BASELINE configs[3] beside the headline (outside the timed region): the sampling decode of generate.py /
+    visual_dialog_model.py:86-111 (16 rows x 18 token steps, KV cache, the token loop replayed as one hipGraph) and the
+    evaluate_gen.py:76-106 candidate scoring (one 500-row chunk = 5 rounds x 100 options, encode-once vs the reference's expanded
+    batch), bf16, full-size model, synthetic inputs resident in HBM."""
+    model, params = build_model(device, "bf16", seed=1)
+    model.eval()
+
+    def timeit(fn, n=5, warm=2):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    out = {}
+    with torch.no_grad():
+        params["mode"] = "vd_eval_val"
+        R_, O_ = 5, 100
+        b = synthetic_rows(R_, 256, 37, 25, 2048, V, 5, device)
+        cand = synthetic_rows(R_ * O_, 256, 37, 25, 2048, V, 6, device)
+        enc = [b[k] for k in ("enc_image_features", "enc_image_spatials", "enc_image_mask", "enc_input_ids", "enc_segments", "enc_attention_mask")]
+
+        def once():
+            return model.score_candidates(*enc, cand["dec_input_ids"].clone(), cand["dec_attention_mask"], O_)
+
+        def expanded():
+            rep = lambda x: x.repeat_interleave(O_, 0)          # noqa: E731
+            return model(enc_image_features=rep(enc[0]), enc_image_spatials=rep(enc[1]), enc_image_mask=rep(enc[2]), enc_input_ids=rep(enc[3]),
+                         enc_segments=rep(enc[4]), enc_attention_mask=rep(enc[5]), dec_input_ids=cand["dec_input_ids"].clone(),
+                         dec_attention_mask=cand["dec_attention_mask"], dec_labels=None, loss_reduction=False)
+        t_once = timeit(once)
+        t_exp = timeit(expanded, n=2, warm=1)
+        out["score"] = {"chunk": "5 rounds x 100 options = 500 candidate rows (evaluate_gen.py:29,151)", "encode_once_ms": round(t_once, 2),
+                        "expanded_batch_ms": round(t_exp, 2), "candidates_per_s": round(500e3 / t_once, 1)}
+        params["mode"] = "vd_gen_val"
+        d = synthetic_rows(16, 256, 37, 25, 2048, V, 7, device)
+        kw = {k: d[k] for k in ("enc_image_features", "enc_image_spatials", "enc_image_mask", "enc_input_ids", "enc_segments", "enc_attention_mask")}
+        kw.update(dec_input_ids=torch.full((16, 1), 101, dtype=torch.long, device=device), temperature=0.7, top_k=7, top_p=0.0,
+                  ngram_blocking_size=0)
+        params["amd_decode_graph"] = True
+        t_rep = timeit(lambda: model(**kw))
+        kw["ngram_blocking_size"] = 4               # the questioner's setting (generate.py:138-141)
+        t_ng = timeit(lambda: model(**kw))
+        lpt = getattr(model.engine, "decode_lib_calls_per_token", None)       # counted on the eager first call (each >= 1 launch)
+        out["decode"] = {"rows": 16, "steps": 18, "ms_replayed": round(t_rep, 2), "ms_replayed_ngram4": round(t_ng, 2),
+                         "ms_per_token": round(t_rep / 18, 3), "launches_per_token": round(lpt, 1) if lpt else None, "rows_per_s": round(16e3 / t_rep, 1),
+                         "how": "encoder + cross-K/V once, KV-cached decoder, sampling step on the device, token loop = one hipGraph replay"}
+    del model
+    torch.cuda.empty_cache()
+    return out
 
 
 def demangle(sym):
@@ -166,7 +344,21 @@ def main():
     ap.add_argument("--no-streams", action="store_true", help="run the vision stream on the main HIP stream")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 parity-mode timing beside the bf16 headline")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive measurement (inputs staged from pinned host memory)")
+    ap.add_argument("--no-eval-decode", action="store_true", help="skip the BASELINE configs[3] side measurements (decode / candidate scoring)")
+    ap.add_argument("--legs", default="auto", choices=["auto", "on", "off"],
+                    help="extra N>1 legs beside the headline, each in fresh child processes: 10 rows/rank (BASELINE configs[2]) and the "
+                         "reference-faithful fp32 gradient all-reduce (auto: when more than one rank runs)")
+    ap.add_argument("--leg", default=None, help=argparse.SUPPRESS)          # set by run_leg(): this process IS a leg's rank
     args = ap.parse_args()
+    argv = sys.argv[1:]
+
+    if args.leg is not None:             # a leg's rank: the timed region only, no side measurements, no legs of its own
+        args.no_breakdown = args.no_cpu_baseline = args.no_h2d = args.no_fp32 = args.no_eval_decode = True
+        args.legs = "off"
+
+    # ---- launcher: `--gpus N` with N > 1 and no rank environment -> start the N ranks ourselves (child process, no GPU call here)
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(launcher_main(args.gpus, argv))
 
     # torch's OpenMP pool on a 256-logical-CPU host: workers that keep spinning after a parallel CPU tensor op starve the ROCm
     # runtime's threads and slow hipGraph replays (measured 2x); the GPU legs need no CPU parallelism,
@@ -175,6 +367,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+
+    def leg_port(k):
+        """Rendezvous port of the k-th child leg: every rank derives the same number without talking to the others (the parent's
+        own port stays occupied by its launcher's store for the whole run)."""
+        return int(os.environ.get("MASTER_PORT", "29511")) + 1 + k
+
+    if world != args.gpus:
+        # a --gpus N line from a different number of ranks would be a mislabelled measurement: never print one
+        sys.stderr.write("bench: --gpus %d but WORLD_SIZE = %d: start it as `python bench.py --gpus %d` (self-launching) or under "
+                         "torch.distributed.run --nproc-per-node %d\n" % (args.gpus, world, args.gpus, args.gpus))
+        sys.exit(2)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     # GSTVD_BENCH_ONE_GPU=1 (validation only): run the multi-rank control flow with every rank on cuda:0 and the collectives
@@ -204,7 +407,6 @@ def main():
             from gst_visdial_amd.graph import enable_watchdog_introspection
             enable_watchdog_introspection()      # lets the capture wait until c10d's watchdog has retired the warm-up collectives
             dist.init_process_group("nccl", device_id=device)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     from gst_visdial_amd import ops
     from gst_visdial_amd.optim import FusedAdamW
@@ -303,11 +505,33 @@ def main():
                 # (config.hip_graph = false, config.capture_error) is worth more to a scaling run than no number at all.
                 sys.stderr.write("bench: hipGraph capture of the train step failed on %s (%s)\n"
                                  % ("this rank" if capture_error else "another rank", capture_error))
-                if args.graph == "on":
+                if args.graph == "on" or args.leg is not None:
                     sys.stderr.write("bench: --graph on: refusing to time the host-bound eager path\n")
                     dist.destroy_process_group()
                     sys.exit(3)
                 capture_error = capture_error or "capture failed on another rank"
+                # An invalidated capture can leave the communicator (and c10d's watchdog) in an undefined state: nothing more is
+                # issued on this process group.  The labelled eager measurement runs in FRESH child processes (own group, own
+                # port, --graph off), one per rank; rank 0 relays the child's line with the capture error attached.
+                try:
+                    dist.destroy_process_group()
+                except Exception:          # noqa: BLE001
+                    pass
+                fb = run_leg("eager_fallback", ["--graph", "off"], argv, rank, world, local, leg_port(0))
+                rc = 3
+                if rank == 0:
+                    if fb and "error" not in fb:
+                        fb.setdefault("config", {})["capture_error"] = capture_error
+                        fb["config"]["measured_in"] = "fresh child processes after the failed hipGraph capture (eager issue, host bound)"
+                        fb["config"].pop("leg", None)
+                        _flush_c_stdio()
+                        print(json.dumps(fb), flush=True)
+                        rc = 0
+                    else:
+                        sys.stderr.write("bench: the eager fall-back run failed too (%s)\n" % (fb or {}).get("error"))
+                else:
+                    rc = 0
+                sys.exit(rc)
         if capture_error is None:
             def step():                  # noqa: F811
                 loss = replay()
@@ -433,6 +657,19 @@ def main():
                                   "attention_ms_per_step": round(ca_ms, 3),
                                   "block_frac_incl_attention": round((cg_fl + ca_fl) / ((cg_ms + ca_ms) * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                                   "note": "forward + input-gradient GEMMs of the 6 connection layers; target >= 0.40 (north_star)"}
+        # "HBM GB/s of the bandwidth-bound kernels vs peak" -- algorithmic bytes per launch (the byte counts
+        # ops.py states next to each call: AdamW 30 B/param, LayerNorm 3 / 5 activations per element, CE logits once / twice)
+        # over the HIP-event duration of the same serialized pass, against the 8 TB/s HBM3E peak
+        hbm = []
+        for k in ("adamw", "ln_fwd", "ln_bwd", "ce_fwd", "ce_bwd"):
+            v = agg.get(k)
+            if v and v["bytes"] and v["ms"] > 0:
+                gbs = v["bytes"] / (v["ms"] * 1e-3) / 1e9
+                hbm.append({"kernel": k, "launches": v["launches"], "ms_per_step": round(v["ms"], 3),
+                            "algorithmic_bytes_per_launch": round(v["bytes"] / v["launches"]), "achieved": round(gbs, 1), "unit": "GB/s",
+                            "peak": PEAK_HBM_GBS, "frac": round(gbs / PEAK_HBM_GBS, 4)})
+        roofline["hbm"] = hbm
+        roofline["launching_calls_per_step"] = sum(v["launches"] for v in agg.values())
         breakdown = {k: dict(launches=v["launches"], ms=round(v["ms"], 3),
                              tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None,
                              gbps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None)
@@ -501,6 +738,15 @@ def main():
         except Exception as ex:            # noqa: BLE001 -- a diagnostic beside the headline must not take the line down
             sys.stderr.write("bench: fp32 parity-mode timing skipped (%s: %s)\n" % (type(ex).__name__, ex))
 
+    # ---- BASELINE configs[3] beside the headline: sampling decode + candidate scoring at full size (outside the timed region)
+    side = None
+    if rank == 0 and world == 1 and not args.no_eval_decode and args.precision == "bf16":
+        try:
+            side = eval_decode_side(device, V)
+        except Exception as ex:            # noqa: BLE001 -- a side measurement must not take the line down
+            sys.stderr.write("bench: configs[3] side measurements skipped (%s: %s)\n" % (type(ex).__name__, ex))
+            side = {"error": "%s: %s" % (type(ex).__name__, ex)}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(model, T, R, U, F, V)
@@ -514,7 +760,7 @@ def main():
                                       "seq_len %d, 37x2048 region features, answer len 25 [%s]"
                                       % (B, T, "BASELINE configs[1] per-GPU shape" if B == 16 else
                                          "BASELINE configs[2] per-rank shape (global 80 at 8 GPUs)" if B == 10 else "custom rows/GPU"),
-                          "global_batch": B * world, "seq_len": T, "parallelism": "dp%d" % world,
+                          "global_batch": B * world, "rows_per_gpu": B, "seq_len": T, "parallelism": "dp%d" % world, "leg": args.leg,
                           "gpu_ms_per_step_events": round(e0.elapsed_time(e1) / args.steps, 3), "eager_host_issue_ms_per_step": round(host_ms, 3), "hip_graph": bool(use_graph), "capture_error": capture_error_msg,
                           "final_loss": round(final_loss, 4)},
                "roofline": roofline, "cpu_baseline": cpu}
@@ -526,15 +772,41 @@ def main():
         # many ranks, with which payload); summing bf16 payloads IN bf16 deviates from the reference's fp32 reduce-add by
         # <= 4e-3 of a tensor's norm at 8 ranks (tests/test_dp_gloo.py::test_eight_rank_graded_slices_bf16_payload_error_bound)
         out["config"]["rccl"] = rccl_info if collective else None
-        out["config"]["dropout_seed_per_rank"] = True
+        out["config"]["dropout_seed_per_rank"] = bool(params.get("amd_seed_per_rank", True)) if collective else None
+        # what the driver needs to turn per-N values into a scaling curve (weak scaling: rows/GPU fixed, so scaling(N) = value_N / value_1)
+        out["config"]["scaling_inputs"] = {"rows_per_gpu": B, "global_batch": B * world, "payload_dtype": (compress or "fp32") if collective else None,
+                                           "scaling_vs_n1": "value(N) / value(1) at equal rows_per_gpu; bench.py never reports efficiency itself"}
         from gst_visdial_amd import graph as _g
         out["config"]["capture_quiesce"] = _g.LAST_QUIESCE[0] if use_graph else None
         out["config"]["fp32_parity_mode_ms_per_step"] = fp32_ms
         out["config"]["pcie_inclusive"] = pcie
+        out["config"]["decode"] = (side or {}).get("decode") if side and "error" not in side else side
+        out["config"]["score"] = (side or {}).get("score") if side and "error" not in side else None
     if world > 1 or force_dist:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()          # RCCL prints its banner here; the JSON line must come last
+    # ---- extra legs beside the headline (N > 1): the same step at 10 rows/rank (BASELINE configs[2]: global 80 at 8 GPUs) and with
+    # the reference-faithful fp32 gradient all-reduce (train_gen.py:324 reduce-adds fp32; the headline's payload is bf16).  Fresh
+    # child processes per rank, after this process's group is gone; a failed leg is reported as {"error": ...} in its slot.
+    if args.leg is None and (args.legs == "on" or (args.legs == "auto" and world > 1)):
+        legs = []
+        if B != 10:
+            legs.append(("rows10", ["--rows-per-gpu", "10"]))
+        if compress is not None:
+            legs.append(("fp32_allreduce", ["--grad-compress", "none"]))
+        for k, (name, extra) in enumerate(legs):
+            res = run_leg(name, extra, argv, rank, world, local, leg_port(1 + k))
+            if rank == 0:
+                if res and "error" not in res:
+                    c = res.get("config", {})
+                    res = {"value": res.get("value"), "unit": res.get("unit"), "ms_per_step": res.get("ms_per_step"), "n_gpus": res.get("n_gpus"),
+                           "rows_per_gpu": c.get("rows_per_gpu"), "global_batch": c.get("global_batch"), "hip_graph": c.get("hip_graph"),
+                           "grad_allreduce_dtype": c.get("grad_allreduce_dtype"),
+                           "ranks_seen_by_allreduce": (c.get("rccl") or {}).get("ranks_seen_by_allreduce"), "workload": c.get("workload")}
+                out["config"].setdefault("legs", {})[name] = res
+                if name == "rows10" and world == 8:
+                    out["config"]["global80"] = res      # BASELINE configs[2] exactly: batch 80 global over 8 GPUs
     _flush_c_stdio()                          # ... and it sits in the C stdio buffer: push it out before our line
     if rank == 0:
         sys.stdout.flush()

@@ -145,7 +145,11 @@ def load():
     return lib
 
 
+N_CALLS = [0]      # launching library calls made so far (each is >= 1 kernel launch): bench.py reports calls per decode token
+
+
 def check(name, rc):
+    N_CALLS[0] += 1
     if rc != 0:
         what = _STATUS.get(rc, "hipError_t %d" % rc if rc > 0 else "status %d" % rc)
         raise GstvdError("%s failed: %s" % (name, what))

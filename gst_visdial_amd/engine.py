@@ -29,6 +29,7 @@ import weakref
 import torch
 
 from . import ops
+from . import _lib as _libmod
 from .config import encoder_schedule
 from ._lib import GstvdError, EPI_GELU, EPI_DGELU, LN_RESID, LN_EMBED, LN_IMAGE
 
@@ -1225,10 +1226,12 @@ class Engine(object):
             hist = ids * (segs == 0).long()
             cur = torch.zeros(L0 + max_seq_len, Bn, dtype=torch.long, device=ids.device)
             cur[:L0] = dec_ids.t()
+            calls0 = _libmod.N_CALLS[0]
             for t in range(L0 + max_seq_len - 1):
                 logits = one_token(cur[t], t)
                 if t >= L0 - 1:                            # (earlier positions only consume the given prefix)
                     self._sampling_step(logits, cur, t + 1, hist, P, u[t - (L0 - 1)])
+            self.decode_lib_calls_per_token = (_libmod.N_CALLS[0] - calls0) / float(L0 + max_seq_len - 1)
         self.last = dict(decode_logits=logits.float())    # last position's raw logits (tests / debugging)
         # the encoder side of this call (cross-attention K/V of all layers, masks) stays valid in the arena until the next
         # engine call: `rescore_sampled` scores the sampled answer against it without a second encoder pass

@@ -510,15 +510,19 @@ def attn_bwd(a, dO, dQ, dK, dV, delta, lddo=None, lddq=None, lddk=None, lddv=Non
 
 def ce_fwd(logits, labels, M, V, row_loss, lse, stats, ignore_index=0):
     lib = L.load()
+    e0 = _prof_begin()
     L.check("gstvd_ce_fwd", lib.gstvd_ce_fwd(_p(logits), logits.stride(-2), _p(labels), M, V, ignore_index, dt(logits),
                                              _p(row_loss), _p(lse), _p(stats), _stream()))
+    _prof_end(e0, "ce_fwd", 0.0, float(M) * V * logits.element_size(), (M, V))
 
 
 def ce_bwd(logits, labels, lse, stats, gscale, mean, M, V, dlogits, ignore_index=0):
     lib = L.load()
+    e0 = _prof_begin()
     L.check("gstvd_ce_bwd", lib.gstvd_ce_bwd(_p(logits), logits.stride(-2), _p(labels), _p(lse), _p(stats), _p(gscale),
                                              int(mean), M, V, ignore_index, dt(logits), _p(dlogits), dlogits.stride(-2),
                                              _stream()))
+    _prof_end(e0, "ce_bwd", 0.0, float(M) * V * (logits.element_size() + dlogits.element_size()), (M, V))
 
 
 SAMPLE_MAX_TOP_K = 64      # beyond this (or with top-p) the filter runs as torch ops (decoding.batch_top_k_top_p_sampling)
