@@ -134,8 +134,10 @@ def run_leg(name, extra, base_argv, rank, world, local, port, timeout=420):
     rank (own process group on its own port, own hipGraph capture): a failure there costs that leg, never the headline line.
     Every rank calls this with the same arguments after the parent's process group is gone; rank 0 returns the leg's JSON."""
     import subprocess
-    env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local), MASTER_ADDR="127.0.0.1",
-               MASTER_PORT=str(port))
+    # (without the elastic agent's variables: TORCHELASTIC_USE_AGENT_STORE would make rank 0 of the leg look for the PARENT
+    # launcher's store on the leg's port instead of opening its own -- the leg's rendezvous then waits for ever)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+    env.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     cmd = [sys.executable, os.path.abspath(__file__)] + list(base_argv) + list(extra) + ["--leg", name]
     try:
         r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, timeout=timeout)

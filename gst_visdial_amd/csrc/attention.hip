@@ -210,7 +210,7 @@ DEVFN void second_product_pair(f32x4 (&acc)[D / 16], const char* img_tr, int xb,
 // Dropout draws.  E32: the launch has fewer than 2^33 score elements, so the high word of every pair index is zero and its
 // term of drop_draw (a quarter-rate integer multiply per draw) vanishes -- same stream, cheaper arithmetic.
 template <bool E32> DEVFN uint32_t draw_pair(const DropKey& k, uint64_t e2) {
-  if (E32) return mix32((uint32_t)e2 ^ k.key);
+  if (E32) return drop_hash((uint32_t)e2, k.key);
   return drop_draw(k, e2);
 }
 template <bool E32> DEVFN f32x4 drop_factor4e(const DropKey& k, uint64_t e) {      // four consecutive elements, e % 4 == 0

@@ -98,6 +98,16 @@ DEVFN uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x = __umul24(x, 0xeb352dU); x ^= x >> 15; x = __umul24(x, 0x6ca68bU); x ^= x >> 16;
   return x;
 }
+// Draw for 32-bit counter c under `key`.  mix32's first multiply reads 24 bits: after the xor-fold the counter's TOP BYTE meets
+// them only linearly (in bits 8..15), so c and c ^ 0x01000100 gave the same draw for every key -- exact duplicates of the mask
+// at a fixed distance as soon as a site has more than 2^24 draws (2^25 elements: attention probabilities at >= 43 rows x 12
+// heads x 256 x 256).  The top byte is therefore hashed into the key first (8 bits x a 24-bit odd constant, a full-rate
+// v_mul_u32_u24; it is zero -- and the stream unchanged -- for the first 2^24 counters of a site): counters that differ in bits
+// 24..31 now collide only like any two unrelated counters (tests/test_host_logic.py restates this hash in numpy and checks
+// both; tests/test_ops_gpu.py checks the device masks of a 2^26-element site).
+DEVFN uint32_t drop_hash(uint32_t c, uint32_t key) {
+  return mix32(c ^ key ^ __umul24(c >> 24, 0x9E3779u));
+}
 struct DropKey {
   uint32_t key, thr;   // keep iff u16 >= thr
   float scale;         // 1/(1-p)
@@ -121,7 +131,7 @@ DEVFN DropKey make_drop(float p, uint32_t site, const uint64_t* rng) {
 }
 DEVFN uint32_t drop_draw(const DropKey& k, uint64_t e2) {   // e2 = element index >> 1
   uint32_t lo = (uint32_t)e2, hi = (uint32_t)(e2 >> 32);
-  return mix32((lo ^ k.key) + hi * 0x9E3779B1u);
+  return mix32((lo ^ k.key ^ __umul24(lo >> 24, 0x9E3779u)) + hi * 0x9E3779B1u);
 }
 DEVFN float drop_factor(const DropKey& k, uint64_t e) {     // scale if kept, 0 if dropped
   if (!k.on) return 1.f;

@@ -596,8 +596,11 @@ class Engine(object):
     def _ln_bwd(self, kw, x, res, y, g, b, H, bias_name):
         M = x.M
         prod = x.prod
+        # (prod[0] must be a third tensor: for LN(Linear(r) + r) the input gradient of the Linear and the residual gradient are the
+        # SAME tensor's gradient -- the fused launch would hand one uninitialised buffer to both its `dres` column tile and its
+        # dgrad addend/C, an intra-kernel race; such a site takes the two-launch path, which accumulates correctly)
         if (self.fuse_ln and prod is not None and prod[3] and res is not None and prod[0].N == prod[2]
-                and ops.gemm_ln_ok(M, prod[2], H, x.t.dtype)):
+                and prod[0] is not res and prod[0] is not x and ops.gemm_ln_ok(M, prod[2], H, self.adt)):
             # the LayerNorm's backward and the input gradient of the Linear that produced its input, one launch
             # (gstvd_gemm_ln_bwd): dx never travels through HBM between the two, one dependent launch less per sub-layer
             xin, w, Kin, _ = prod

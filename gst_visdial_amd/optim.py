@@ -99,7 +99,8 @@ class FusedAdamW(object):
         self.base = base
         self.hp_host = torch.empty(len(base) * 2, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.empty(len(base) * 2)
         self.hp = torch.empty(len(base) * 2, dtype=torch.float32, device=dev)
-        self._sync_step()                      # (a rebuild after replayed steps: the device counter is the truth)
+        if self._pending is None:              # (a rebuild after replayed steps: the device counter is the truth -- unless a
+            self._sync_step()                  #  checkpoint is queued: its opt_step must not be overwritten by the stale counter)
         old = (self.m, self.v) if self._built and self.m.numel() == flat.P.numel() else None
         self.m = torch.zeros_like(flat.P)
         self.v = torch.zeros_like(flat.P)
@@ -118,6 +119,11 @@ class FusedAdamW(object):
         at capture; the captured `step_dev += 1` then advances on the device with every replay while the host copy stands
         still -- a checkpoint written from the host copy would restart AdamW's bias correction near t = 1 on warm moments."""
         if self._built:
+            if self.step_dev.is_cuda and torch.cuda.is_current_stream_capturing():
+                # .item() is a device synchronisation: inside a stream capture it would invalidate the capture (and, at N>1, take
+                # the c10d watchdog down with it).  A rebuild of the optimizer state belongs in front of the capture.
+                raise RuntimeError("FusedAdamW: the optimizer state has to be (re)built while a hipGraph capture is running (the flat "
+                                   "parameter buffer was re-materialised?) -- run one eager step, or call state_dict(), before capturing")
             self.opt_step = int(round(float(self.step_dev.item())))
         return self.opt_step
 

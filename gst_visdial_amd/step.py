@@ -88,6 +88,7 @@ class PinnedStager(object):
         self.copied = [None] * depth          # pinned_async: this slot's H2D has finished
         self.consumed = [None] * depth        # pinned_async: event behind the compute that read this slot's device buffers
         self.last_slot = None                 # slot handed out by the latest upload(); its consumer is enqueued AFTER that call
+        self._consumer_stream = None          # ... on this stream (the one upload() made wait for the H2D)
         self._last_marked = True
         self.i = 0
         self.bytes_staged = 0
@@ -105,10 +106,19 @@ class PinnedStager(object):
         the copy stream wait on it.  (Round 2 recorded the event only inside the next upload() of a DIFFERENT slot: with the
         fill-before-upload order of `prefetch()` the H2D of batch k waited on nothing relevant and could overwrite the rows
         step k-2 -- forward and, in eager mode, backward -- was still reading; a host that runs ahead of the device, as the
-        reference loop with its one sync per 10 iterations does, exposes it.)  Call the stager from the consuming stream."""
+        reference loop with its one sync per 10 iterations does, exposes it.)  The event is recorded on the stream upload() saw."""
         if self.mode == "pinned_async" and self.last_slot is not None and not self._last_marked:
+            # on the stream `upload()` ordered the rows on -- NOT on whatever stream is current now: a caller that runs the step
+            # inside `with torch.cuda.stream(s):` but pulls the prefetch generator outside that context would otherwise record
+            # on the default stream and the copy stream could overwrite rows the step on `s` is still reading (ADVICE r3)
+            self.mark_consumed(self._consumer_stream)
+
+    def mark_consumed(self, stream=None):
+        """Explicit form: "the consumer of the latest upload()'s rows has been enqueued on `stream`" (default: the stream that
+        upload() ordered them on).  A caller whose step runs on yet another stream than the one upload() saw calls this."""
+        if self.mode == "pinned_async" and self.last_slot is not None:
             done = torch.cuda.Event()
-            done.record(torch.cuda.current_stream(self.device))
+            done.record(stream if stream is not None else (self._consumer_stream or torch.cuda.current_stream(self.device)))
             self.consumed[self.last_slot] = done
             self._last_marked = True
 
@@ -147,7 +157,7 @@ class PinnedStager(object):
         if self.mode == "pinned_async":
             cur = torch.cuda.current_stream(self.device)
             cur.wait_event(ev)
-            self.last_slot, self._last_marked = slot, False
+            self.last_slot, self._last_marked, self._consumer_stream = slot, False, cur
             out.update({k: self.dev[slot][k] for k in keys})
             return out
         for k in keys:

@@ -149,7 +149,8 @@ int gstvd_ln_bwd(const gstvd_ln_bwd_t* p, gstvd_stream_t s);
  *                       lb->dres, lb->dx and lb->partial = [ceil(M/R), 3, H] column partials, R = gstvd_gemm_ln_rows_per_block();
  *                       lb->nblk must be ceil(M/R)
  * Constraints: H = K a multiple of 64 and <= 768, M <= 1024, N >= 640 and N % 8 == 0.  GSTVD_E_UNSUPPORTED otherwise (the caller
- * runs the two kernels separately). */
+ * runs the two kernels separately).  M <= 1024 is what the KERNEL accepts; the host policy (ops.gemm_ln_ok) only sends M <= 640
+ * and at most 512 workgroups (one round of the chip) -- beyond that the two plain kernels are faster. */
 int gstvd_gemm_ln_fwd(const gstvd_gemm_t* g, const gstvd_ln_t* ln, gstvd_stream_t s);
 int gstvd_gemm_ln_bwd(const gstvd_gemm_t* g, const gstvd_ln_bwd_t* lb, gstvd_stream_t s);
 int64_t gstvd_gemm_ln_rows_per_block(void);

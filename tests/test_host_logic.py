@@ -356,3 +356,52 @@ def test_rank_seed_gives_every_rank_its_own_dropout_stream():
     seeds = [ops.rank_seed(1234, r) for r in range(8)]
     assert seeds[0] == 1234 and len(set(seeds)) == 8 and all(0 <= s < 2 ** 63 for s in seeds)
     assert len({s & 0xffffffff for s in seeds}) == 8 and len({s >> 32 for s in seeds}) == 8     # both words the kernels hash differ
+
+
+def _np_mix32(x):
+    """csrc/common.h mix32 restated in numpy (uint32 wrap-around arithmetic; __umul24 = product of the low 24 bits, low 32 kept)."""
+    import numpy as np
+    x = x.astype(np.uint64)
+    m = np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(16); x = ((x & np.uint64(0xFFFFFF)) * np.uint64(0xeb352d)) & m
+    x ^= x >> np.uint64(15); x = ((x & np.uint64(0xFFFFFF)) * np.uint64(0x6ca68b)) & m
+    x ^= x >> np.uint64(16)
+    return x.astype(np.uint32)
+
+
+def _np_drop_hash(c, key):
+    import numpy as np
+    c = c.astype(np.uint64)
+    t = ((c >> np.uint64(24)) * np.uint64(0x9E3779)) & np.uint64(0xFFFFFFFF)
+    return _np_mix32((c ^ np.uint64(key) ^ t) & np.uint64(0xFFFFFFFF))
+
+
+def test_dropout_counter_hash_has_no_structured_top_byte_collisions():
+    """the 24-bit multiplies of mix32 dropped the counter's top byte -- mix32(c ^ key) == mix32((c ^ 0x01000100) ^ key)
+    for EVERY c and key, i.e. exact mask duplicates at a fixed distance once a site has more than 2^24 draws.  drop_hash (the
+    top byte hashed into the key first) must (a) leave the first 2^24 counters' stream unchanged, (b) have no such pair."""
+    import numpy as np
+    rs = np.random.RandomState(0)
+    c = rs.randint(0, 2 ** 32, size=1 << 18, dtype=np.uint64).astype(np.uint32)
+    for key in (0, 0x12345678, 0xdeadbeef):
+        old = _np_mix32(c ^ np.uint32(key))
+        assert np.array_equal(old, _np_mix32((c ^ np.uint32(0x01000100)) ^ np.uint32(key)))      # the defect, restated
+        new = _np_drop_hash(c, key)
+        low = c < (1 << 24)
+        assert np.array_equal(new[low], old[low])                                                   # (a)
+        for flip in (0x01000100, 0x02000200, 0x80008000, 0x01000000, 0xff000000, 0x81008100):
+            same = (new == _np_drop_hash(c ^ np.uint32(flip), key)).mean()
+            assert same < 1e-3, (hex(key), hex(flip), same)                                       # (b): unrelated draws
+    # counters that differ ONLY in bits 24..31 (256 blocks of one low part): all 256 draws distinct for almost every low part
+    lowpart = rs.randint(0, 1 << 24, size=4096).astype(np.uint32)
+    blocks = (np.arange(256, dtype=np.uint32)[:, None] << np.uint32(24)) | lowpart[None, :]
+    d = _np_drop_hash(blocks.reshape(-1), 0x9e3779b9).reshape(256, -1)
+    distinct = np.array([len(np.unique(d[:, j])) for j in range(d.shape[1])])
+    assert (distinct >= 255).mean() > 0.99 and distinct.min() >= 250
+    # sequential counters across a 2^24 boundary keep the keep-rate and show no lag-2^24 correlation
+    seq = np.arange((1 << 24) - (1 << 16), (1 << 24) + (1 << 16), dtype=np.uint32)
+    keep = (_np_drop_hash(seq, 0x1234) & 0xffff) >= int(0.1 * 65536 + 0.5)
+    assert abs(keep.mean() - 0.9) < 5e-3
+    a = (_np_drop_hash(seq[: 1 << 16], 0x1234) & 0xffff) >= 6554
+    b = (_np_drop_hash(seq[: 1 << 16] + np.uint32(1 << 24), 0x1234) & 0xffff) >= 6554
+    assert abs((a == b).mean() - (0.81 + 0.01)) < 0.01

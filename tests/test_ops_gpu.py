@@ -139,6 +139,23 @@ def test_gemm_splitk_matches_single_pass(lay, shape):
     assert (outs[0].float() - C1.float()).abs().max() <= 2.0 ** -7 * ref.abs().max()
 
 
+def test_dropout_masks_of_a_site_larger_than_2p24_draws_do_not_repeat():
+    """a site with more than 2^24 draws (2^25 elements) got exactly duplicated mask pairs at XOR distance 0x01000100
+    of the pair counter.  Device masks of a 2^26-element site: the keep bits at that distance must be independent
+    (agreement p^2 + (1-p)^2), and the first 2^25 elements are the stream the smaller sites have always had."""
+    o = ops()
+    rng = o.Rng(DEV, seed=77)
+    n, p = 1 << 26, 0.25
+    keep = o.dropout_mask(n, p, 5, rng, DEV) != 0
+    assert abs(keep.float().mean().item() - (1 - p)) < 1e-3
+    e = torch.arange(1 << 22, device=DEV) + (1 << 23)                   # some elements of the first 2^24-draw block
+    partner = (((e >> 1) ^ 0x01000100) << 1) | (e & 1)                  # the element whose pair counter differs in bits 8 and 24
+    agree = (keep[e] == keep[partner]).float().mean().item()
+    assert abs(agree - (p * p + (1 - p) * (1 - p))) < 5e-3, agree      # 0.625; the defect gave 1.0
+    small = o.dropout_mask(1 << 20, p, 5, rng, DEV) != 0
+    assert torch.equal(small, keep[: 1 << 20])
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_batched_and_dropout(dtype):
     o = ops()

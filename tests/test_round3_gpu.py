@@ -268,6 +268,31 @@ def test_stager_never_overwrites_a_slot_its_consumer_is_still_reading():
         assert torch.equal(out.cpu(), want), (order, out.cpu(), want)
 
 
+def test_stager_consumed_event_follows_the_consumer_stream_not_the_current_one():
+    """the step runs inside `with torch.cuda.stream(side)` (upload() is called there, so the rows are ordered on
+    `side`), but the NEXT fill() is called outside that context, on the default stream.  The slot's consumed-event must be
+    recorded on `side`: recorded on the idle default stream it is complete at once and the copy stream overwrites rows the
+    spinning consumer has not read yet."""
+    from gst_visdial_amd import step
+    n, rows_n = 8, 1 << 16
+    host = [dict(x=torch.full((rows_n,), float(k + 1))) for k in range(n)]
+    side = torch.cuda.Stream(device=DEV)
+    st = step.PinnedStager(DEV, depth=2)
+    out = torch.zeros(n, 2, device=DEV)
+    pending = st.fill(host[0])
+    for k in range(n):
+        with torch.cuda.stream(side):
+            rows = st.upload(pending)
+            torch.cuda._sleep(20_000_000)
+            out[k, 0] = rows["x"].sum()
+            out[k, 1] = rows["x"].min() - rows["x"].max()
+        if k + 1 < n:
+            pending = st.fill(host[k + 1])            # default stream is current here
+    torch.cuda.synchronize()
+    want = torch.tensor([[float(h["x"].sum()), 0.0] for h in host])
+    assert torch.equal(out.cpu(), want), (out.cpu(), want)
+
+
 # ---- ADVICE r2 (medium): optimizer step count in checkpoints written after hipGraph-replayed training --------------------
 @pytest.mark.isolated
 def test_checkpoint_after_graph_replays_records_the_device_step_count_and_resumes_identically(tmp_path):

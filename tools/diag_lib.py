@@ -16,7 +16,7 @@ if ROOT not in sys.path:
 def use(build=True):
     from gst_visdial_amd import _lib
     path = os.path.join(ROOT, "gst_visdial_amd", "lib", "libgstvd_hip_diag.so")
-    if build and not os.path.exists(path):
+    if build:       # always: make is incremental, and a library that merely EXISTS may predate the last source edit
         subprocess.run(["make", "-C", os.path.join(ROOT, "gst_visdial_amd", "csrc"), "-j4", "diag"], check=True)
     if _lib._lib is not None:
         raise RuntimeError("diag_lib.use() must run before the product library is loaded")
