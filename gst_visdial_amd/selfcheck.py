@@ -16,9 +16,11 @@ def load_npz(name):
         return {k: torch.from_numpy(z[k]) for k in z.files}
 
 
-def build_tiny_model(precision="fp32", device="cuda:0", mode="vd_train", seed=0, cfg_file="tiny_cfg.json", **extra_params):
+def build_tiny_model(precision="fp32", device="cuda:0", mode="vd_train", seed=0, cfg_file="tiny_cfg.json", state_file="tiny_state.npz",
+                     **extra_params):
     """The tiny-config model of the golden fixtures, weights from tests/golden/tiny_state.npz.  `cfg_file`:
-    "tiny_cfg_dropout.json" is the same architecture with a different dropout probability per family (train-mode parity)."""
+    "tiny_cfg_dropout.json" is the same architecture with a different dropout probability per family (train-mode parity);
+    `state_file`: "tiny_state_trained.npz" is the TRAINED tiny checkpoint of oracle/make_golden_r4.py (peaked answer distributions)."""
     from .modules import VisualDialogEncoder, VisualDialogDecoder, EncoderDecoderModel
     with open(os.path.join(GOLDEN, cfg_file)) as f:
         cfg = json.load(f)
@@ -34,8 +36,24 @@ def build_tiny_model(precision="fp32", device="cuda:0", mode="vd_train", seed=0,
     enc, dec = VisualDialogEncoder(params), VisualDialogDecoder(params)
     model = EncoderDecoderModel(params, enc, dec)
     dec.decoder.bert.embeddings = enc.bert_pretrained.bert.embeddings          # train_gen.py:293
-    model.load_state_dict(load_npz("tiny_state.npz"), strict=True)
+    model.load_state_dict(load_npz(state_file), strict=True)
     return model.to(device), params, cfg
+
+
+def evalset100_batches(ev, dialogs_per_batch=2):
+    """tests/golden/tiny_evalset100.npz -> batches in the eval dataloader's layout: the fixture stores a
+    round's context once; the loader repeats it for each of the round's 100 options (dataloader_visdial_gen.py:379-388)."""
+    b = {k[4:]: v for k, v in ev.items() if k.startswith("in::")}
+    G = b["dec_input_ids"].shape[2]
+    ids = b["enc_input_ids"].long()
+    full = dict(enc_input_ids=ids[:, :, None].expand(-1, -1, G, -1).contiguous(),
+                enc_segments=b["enc_segments"].long()[:, :, None].expand(-1, -1, G, -1).contiguous(),
+                dec_input_ids=b["dec_input_ids"].long(), dec_att_mask=b["dec_att_mask"], enc_image_feat=b["enc_image_feat"],
+                enc_image_loc=b["enc_image_loc"], enc_image_mask=b["enc_image_mask"], gt_option_inds=b["gt_option_inds"],
+                gt_relevance=b["gt_relevance"], round_id=b["round_id"])
+    full["enc_att_mask"] = (full["enc_input_ids"] != 0).float()
+    n = ids.shape[0]
+    return [{k: v[s:s + dialogs_per_batch].clone() for k, v in full.items()} for s in range(0, n, dialogs_per_batch)]
 
 
 def golden_batch(g, device, dec_key="in::dec_input_ids", with_labels=True):

@@ -121,6 +121,229 @@ def test_full_model_seq_len_256_train_mode_matches_oracle_under_engine_masks(ful
         model.zero_grad(set_to_none=True)
 
 
+def test_full_size_dataparallel_wrapping_checkpoint_load_and_14_kwarg_call(full_fp32, tmp_path):
+    """train_gen.py:293-295,118-135,324 at the reference's model size: nn.DataParallel(model, [0]), a checkpoint written and read
+    the scripts' way (torch.save({'model_state_dict': ...}) / torch.load(map_location=device) / .module.load_state_dict), the 14
+    keyword names incl. the dead inputs, lm_loss.mean().backward() -- logits / loss / gradients against the oracle."""
+    import torch.nn as nn
+    import bench
+    model32, batch, sd, cpu_batch, keys, ref = full_fp32
+    device = torch.device(DEV)
+    model, params = bench.build_model(device, "fp32", seed=99)                    # different weights: the load must matter
+    model = nn.DataParallel(model, params["gpu_ids"])
+    ck = str(tmp_path / "full.ckpt")
+    torch.save({"model_state_dict": sd, "iter_id": 0}, ck)
+    state = torch.load(ck, map_location=device)
+    res = model.module.load_state_dict(state["model_state_dict"])
+    assert not res.missing_keys and not res.unexpected_keys
+    del state
+    model.eval()
+    B, T = batch["enc_input_ids"].shape
+    R = batch["enc_image_features"].shape[1]
+    kw = dict(batch)
+    kw.update(enc_image_target=torch.zeros(B, R, 1601, device=device), enc_image_label=torch.zeros(B, R, dtype=torch.long, device=device),
+              enc_next_sentence_labels=torch.full((B,), -1, dtype=torch.long, device=device),
+              enc_sep_indices=torch.zeros(B, 25, dtype=torch.long, device=device),
+              enc_mlm_labels=torch.full((B, T), -1, dtype=torch.long, device=device))
+    assert len(kw) == 14
+    lm_loss, lm_scores = model(**kw)
+    lm_loss = lm_loss.mean()
+    assert (lm_scores.float().cpu() - ref["logits"]).abs().max().item() <= 1e-4
+    assert abs(lm_loss.item() - ref["loss"].item()) <= 1e-5 * max(1.0, abs(ref["loss"].item()))
+    lm_loss.backward()
+    named = dict(model.module.named_parameters())
+    worst = {k: _rel(named[k].grad, ref["grads"][k]) for k in keys if k in named}
+    assert len(worst) >= 8 and max(worst.values()) <= 5e-4, worst
+
+
+@pytest.mark.isolated
+def test_full_size_questioner_decode_with_4gram_blocking_through_the_wrapper(full_fp32):
+    """generate.py:124-142 at full size: q_model = nn.DataParallel(...); q_model(..., temperature=0.7, top_k, top_p=0.0,
+    ngram_blocking_size=4).  Random-init contexts never repeat a 4-gram by themselves, so the ban is made to bite: the greedy
+    sequence s of a first call (no ban) is planted, as question-segment tokens, into the PADDING of the context rows (history =
+    enc_input_ids * (segments == 0), utils/decoding_utils.py:38-77 -- the attention mask plays no part in it, the encoder output
+    of the real positions is unchanged).  With the ban on, the decode must follow s up to the first position whose token would
+    complete a planted 4-gram and deviate exactly there; fp32 ids equal the oracle's decode on the same inputs (2 rows), and the
+    bf16 engine at 16 rows shows the same property, eager and replayed."""
+    import torch.nn as nn
+    import bench
+    from gst_visdial_amd.config import bert_base_enc_config, bert_base_dec_config
+    O = _oracle()
+    model32, _, sd, _, _, _ = full_fp32
+    device = torch.device(DEV)
+    V = model32.decoder.config.vocab_size
+    special = {0, 100, 101, 102, 103}
+
+    def run(model, rows, ngram, Bn):
+        kw = {k: rows[k] for k in ("enc_image_features", "enc_image_spatials", "enc_image_mask", "enc_input_ids", "enc_segments",
+                                   "enc_attention_mask")}
+        with torch.no_grad():
+            return model(enc_image_target=None, enc_image_label=None, enc_next_sentence_labels=None, enc_sep_indices=None,
+                         enc_mlm_labels=None, dec_input_ids=torch.full((Bn, 1), 101, dtype=torch.long, device=device),
+                         dec_attention_mask=None, temperature=0.7, top_k=1, top_p=0.0, ngram_blocking_size=ngram, **kw).clone()
+
+    def plant(rows, s, k0=2):
+        """tokens s[k0 .. k0+3] of every row -> the last four (padding) positions of its context, segment 0"""
+        rows = {k: v.clone() for k, v in rows.items()}
+        T = rows["enc_input_ids"].shape[1]
+        assert float(rows["enc_attention_mask"][:, T - 4:].sum()) == 0          # really padding
+        rows["enc_input_ids"][:, T - 4:] = s[:, k0:k0 + 4]
+        rows["enc_segments"][:, T - 4:] = 0
+        return rows
+
+    for precision, Bn in (("fp32", 2), ("bf16", 16)):
+        if precision == "fp32":
+            model = model32
+        else:
+            model, _ = bench.build_model(device, "bf16", seed=7)
+            model.load_state_dict({k: v.to(device) for k, v in sd.items()}, strict=True)
+        model.eval()
+        mode = model.params["mode"]
+        model.params["mode"] = "vd_gen_val"
+        wrapped = nn.DataParallel(model, [0])
+        try:
+            rows = bench.synthetic_rows(Bn, 256, 37, 25, 2048, V, 555, device)
+            lens = rows["enc_attention_mask"].sum(1)
+            keep = lens <= 250                                                   # rows with at least 6 padding positions
+            if int(keep.sum()) < Bn:                                             # shorten the others: mask + ids of the tail go to 0
+                rows["enc_input_ids"][:, 250:] = 0
+                rows["enc_segments"][:, 250:] = 0
+                rows["enc_attention_mask"][:, 250:] = 0
+            s = run(wrapped, rows, 0, Bn)                                        # greedy, no ban
+            ok = torch.tensor([not (special & set(s[b, 2:6].tolist())) for b in range(Bn)])
+            assert int(ok.sum()) >= max(1, Bn // 2)                              # greedy rows that do not hit a special token early
+            planted = plant(rows, s)
+            same = run(wrapped, planted, 0, Bn)
+            assert torch.equal(same, s)                                          # padding content does not change the model's outputs
+            banned = run(wrapped, planted, 4, Bn)
+            for b in range(Bn):
+                if not ok[b]:
+                    continue
+                assert torch.equal(banned[b, :5], s[b, :5]), (precision, b)      # s[2..4] reproduced ...
+                assert banned[b, 5].item() != s[b, 5].item(), (precision, b)     # ... and s[5] would complete the planted 4-gram
+            if precision == "bf16":
+                again = run(wrapped, planted, 4, Bn)                             # second call with these settings: hipGraph replay
+                assert torch.equal(again, banned)
+            else:
+                cpu = {k: v.cpu() for k, v in planted.items()}
+                cpu["dec_input_ids"] = torch.full((Bn, 1), 101, dtype=torch.long)
+                torch.set_num_threads(min(os.cpu_count() or 1, 16))
+                want, _ = O.sampling_decode(sd, bert_base_enc_config(), bert_base_dec_config(), cpu, 0.7, 1, 0.0, 4,
+                                            draw=lambda p: p.argmax(-1, keepdim=True))
+                assert torch.equal(banned.cpu(), want)
+        finally:
+            model.params["mode"] = mode
+
+
+def _cc12m_loader_batch(n_dialogs, V, seed, zero_label_rate=0.4, T=256, R=37, U=25, F=2048):
+    """A batch as the CC12M train loader emits it (SURVEY appendix B; dataloader/dataloader_cc12m_gen.py:193-200,238-266;
+    utils/data_utils.py:89-101): per dialog [10, 1, L] text tensors, encoder inputs with 15 % of the tokens replaced by
+    [MASK] = 103 (mask_prob 0.15; the MLM labels are dead on this path, the masked INPUTS are real), 15 % of the regions chosen
+    and zeroed w.p. 0.9, and -- `-select_data` -- the label rows of the rounds whose answer perplexity is over the threshold zeroed."""
+    import bench
+    g = torch.Generator().manual_seed(seed)
+    rows = bench.synthetic_rows(n_dialogs * 10, T, R, U, F, V, seed, "cpu")
+    ids = rows["enc_input_ids"]
+    special = (ids == 0) | (ids == 101) | (ids == 102)
+    mask_tok = (torch.rand(ids.shape, generator=g) < 0.15) & ~special
+    ids = torch.where(mask_tok, torch.full_like(ids, 103), ids)
+    feats = rows["enc_image_features"][::10].clone()                        # one image per dialog
+    chosen = torch.rand(n_dialogs, R, generator=g) < 0.15
+    zero = chosen & (torch.rand(n_dialogs, R, generator=g) < 0.9)
+    zero[:, 0] = False                                                      # (the global row is built from the boxes before masking)
+    feats[zero] = 0
+    labels = rows["dec_labels"].clone()
+    dropped = torch.rand(n_dialogs * 10, generator=g) < zero_label_rate     # ppl >= threshold
+    dropped[0] = True
+    dropped[1] = False
+    labels[dropped] = 0
+    v = lambda t: t.view(n_dialogs, 10, 1, t.shape[-1])                     # noqa: E731
+    batch = dict(enc_input_ids=v(ids), enc_segments=v(rows["enc_segments"]), enc_att_mask=v((ids != 0).float()),
+                 dec_input_ids=v(rows["dec_input_ids"]), dec_att_mask=v(rows["dec_attention_mask"]), dec_labels=v(labels),
+                 enc_image_feat=feats, enc_image_loc=rows["enc_image_spatials"][::10].clone(), enc_image_mask=torch.ones(n_dialogs, R))
+    return batch, dropped, int(mask_tok.sum()), int(zero.sum())
+
+
+def test_cc12m_self_training_step_full_size_select_data_masked_inputs(full_fp32):
+    """BASELINE configs[4] on the 388 M-parameter model: a cc12m_train-shaped step through the step driver (train_gen.forward,
+    train_gen.py:45-136) -- [MASK]-bearing encoder inputs, zeroed regions, `-select_data` zero-label rows filtered by the row
+    sampler (train_gen.py:65-68).  fp32 parity mode, TRAIN mode (dropout on), 2 sampled rows: logits 1e-4 / loss 1e-5 /
+    gradients 5e-4 against the oracle on exactly the sampled rows under the masks the engine drew; bf16 at the per-rank batch of
+    10 rows: same rows, loss within the bf16 bar of the fp32 engine, every live gradient finite; a batch whose label rows are ALL
+    zero fails loudly, as the reference's torch.multinomial does."""
+    import bench
+    from gst_visdial_amd import selfcheck, step
+    from gst_visdial_amd.config import bert_base_enc_config, bert_base_dec_config
+    model, _, sd, _, keys, _ = full_fp32
+    O = _oracle()
+    V = model.decoder.config.vocab_size
+    batch, dropped, n_mask, n_zero = _cc12m_loader_batch(10, V, 2468)
+    assert n_mask > 1000 and n_zero > 20 and 20 < int(dropped.sum()) < 70
+    dev = torch.device(DEV)
+    params = model.params
+    saved = (params["mode"], params["batch_size"])
+    params["mode"], params["batch_size"], params["device"] = "cc12m_train", 2, dev
+    model.train()
+    try:
+        # ---- the row sampler: only rows with a non-zero label row, same draw as the reference's multinomial on the host RNG
+        gen = torch.Generator().manual_seed(77)
+        rows, idx = step.select_rows(batch, params, None, gen)
+        assert not dropped[idx].any() and (rows["dec_labels"].sum(-1) != 0).all()
+        cand = O.candidate_rows(batch["dec_labels"].view(-1, 25))
+        assert torch.equal(idx, torch.multinomial(cand, 2, replacement=True, generator=torch.Generator().manual_seed(77)))
+        assert int((rows["enc_input_ids"] == 103).sum()) > 10               # the sampled rows really carry [MASK] tokens
+        # ---- fp32, train mode, the two sampled rows vs the oracle under the engine's masks
+        model.zero_grad(set_to_none=True)
+        loss, logits = step.forward(model, batch, params, sample_indices=idx)
+        loss.backward()
+        torch.cuda.synchronize()
+        masks = O.DropMasks(selfcheck.dropout_keep_masks(model.engine))
+        cpu = dict(enc_image_features=rows["enc_image_feat"], enc_image_spatials=rows["enc_image_loc"], enc_image_mask=rows["enc_image_mask"],
+                   enc_input_ids=rows["enc_input_ids"], enc_segments=rows["enc_segments"], enc_attention_mask=rows["enc_att_mask"],
+                   dec_input_ids=rows["dec_input_ids"].clone(), dec_attention_mask=rows["dec_att_mask"], dec_labels=rows["dec_labels"])
+        torch.set_num_threads(min(os.cpu_count() or 1, 16))
+        out, g, _ = O.grads(sd, bert_base_enc_config(), bert_base_dec_config(), cpu, keys, wrt_feats=False, train=masks)
+        assert set(masks.used) == set(model.engine.site_log)
+        err = (logits.float().cpu() - out["logits"]).abs().max().item()
+        assert err <= 1e-4, "cc12m step: fp32 train-mode logits differ from the oracle by %.3e" % err
+        assert abs(loss.item() - out["loss"].item()) <= 1e-5 * max(1.0, abs(out["loss"].item()))
+        named = dict(model.named_parameters())
+        worst = {k: _rel(named[k].grad, g[k]) for k in keys if k in named}
+        assert len(worst) >= 8 and max(worst.values()) <= 5e-4, worst
+        # ---- an all-zero-label batch (every round over the perplexity threshold): loud failure, like torch.multinomial's
+        empty = dict(batch, dec_labels=torch.zeros_like(batch["dec_labels"]))
+        with pytest.raises(RuntimeError):
+            step.forward(model, empty, params)
+        # ---- bf16 at the per-rank batch of BASELINE configs[2] / [4]: 10 rows
+        params["batch_size"] = 10
+        gen = torch.Generator().manual_seed(78)
+        rows10, idx10 = step.select_rows(batch, params, None, gen)
+        assert not dropped[idx10].any()
+        model.eval()                                                            # fp32 engine, dropout off: the bf16 run's yardstick
+        with torch.no_grad():
+            loss32, logits32 = step.forward(model, batch, params, sample_indices=idx10)
+        m16, p16 = bench.build_model(dev, "bf16", seed=7)
+        m16.load_state_dict({k: v.to(dev) for k, v in sd.items()}, strict=True)
+        p16["mode"], p16["batch_size"], p16["device"] = "cc12m_train", 10, dev
+        m16.eval()
+        with torch.no_grad():
+            loss16, logits16 = step.forward(m16, batch, p16, sample_indices=idx10)
+        assert abs(loss16.item() - loss32.item()) <= 3e-2 * max(1.0, abs(loss32.item()))
+        assert (logits16.float() - logits32.float()).abs().max().item() < 0.15
+        m16.train()
+        loss, _ = step.forward(m16, batch, p16, sample_indices=idx10)
+        loss.backward()
+        torch.cuda.synchronize()
+        assert torch.isfinite(loss).all()
+        live = [(n, p) for n, p in m16.named_parameters() if p.grad is not None]
+        assert len(live) > 200 and all(bool(torch.isfinite(p.grad).all()) for _, p in live)
+        assert float(dict(live)["decoder.decoder.lm_head.decoder.weight"].grad.abs().max()) > 0
+    finally:
+        params["mode"], params["batch_size"] = saved
+        model.eval()
+        model.zero_grad(set_to_none=True)
+
+
 def test_full_model_bf16_close_to_oracle(full_fp32):
     import bench
     model32, batch, sd, cpu_batch, keys, ref = full_fp32

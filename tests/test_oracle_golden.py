@@ -291,3 +291,39 @@ def test_injected_masks_are_not_a_no_op(tiny_state, tiny_train):
     import pytest
     with pytest.raises(KeyError):
         O.model_forward(tiny_state, cfg["enc"], cfg["dec"], batch_from_golden(tiny_train), train=O.DropMasks(flipped))
+
+
+# ---- round-4 fixture (oracle/make_golden_r4.py: a TRAINED tiny reference checkpoint scored on 8 x 10 x 100 candidates)
+def test_eval_set_100_options_trained_checkpoint(tiny_cfg):
+    """The oracle on the real-shaped evaluation set (trained tiny checkpoint, 100 options per round, dense relevance): scores of the
+    first two dialogs (2000 rows) to 1e-4, their ranks bit-exact; the metric restatements on the reference's full score tensor."""
+    from conftest import load_npz
+    from gst_visdial_amd.selfcheck import evalset100_batches
+    enc, dec = tiny_cfg
+    ev = load_npz("tiny_evalset100.npz")
+    sd = load_npz("tiny_state_trained.npz")
+    assert ev["min_score_gap"].item() >= 2e-3 - 1e-6            # ranks are a statement about the model, not about summation order
+    batch = evalset100_batches(ev, dialogs_per_batch=2)[0]
+    B, NR, G, T = batch["enc_input_ids"].shape
+    n = B * NR * G
+    dial = torch.arange(B).repeat_interleave(NR * G)
+    b = dict(enc_input_ids=batch["enc_input_ids"].reshape(n, T), enc_segments=batch["enc_segments"].reshape(n, T),
+             enc_attention_mask=batch["enc_att_mask"].reshape(n, T), enc_image_features=batch["enc_image_feat"][dial],
+             enc_image_spatials=batch["enc_image_loc"][dial], enc_image_mask=batch["enc_image_mask"][dial],
+             dec_input_ids=batch["dec_input_ids"].reshape(n, -1).clone(), dec_attention_mask=batch["dec_att_mask"].reshape(n, -1),
+             dec_labels=None)
+    unmutated = b["dec_input_ids"].clone()
+    with torch.no_grad():
+        out = O.model_forward(sd, enc, dec, b)
+    scores = O.answer_scores(out["logits"], unmutated).view(B, NR, G)
+    close(scores, ev["scores"][:B], 1e-4)
+    assert torch.equal(O.scores_to_ranks(scores), ev["ranks"][:B].long())
+    full = ev["scores"]
+    assert torch.equal(O.scores_to_ranks(full), ev["ranks"].long())
+    m = O.sparse_metrics(O.gt_ranks(full, ev["in::gt_option_inds"]))
+    close(torch.tensor([m[k] for k in ("r@1", "r@5", "r@10", "mean", "mrr")], dtype=torch.float64), ev["sparse"], 1e-6)
+    rid = ev["in::round_id"].squeeze(1)
+    nd = O.ndcg_batch(full[torch.arange(full.shape[0]), rid - 1, :], ev["in::gt_relevance"]).mean()
+    close(nd.double().reshape(1), ev["ndcg"].double(), 1e-6)
+    # a checkpoint worth the name: far from the 1 % / 5 % / 10 % of a random ranking
+    assert ev["sparse"][1].item() > 0.3 and ev["sparse"][2].item() > 0.5
