@@ -180,7 +180,12 @@ def test_full_size_questioner_decode_with_4gram_blocking_through_the_wrapper(ful
         with torch.no_grad():
             return model(enc_image_target=None, enc_image_label=None, enc_next_sentence_labels=None, enc_sep_indices=None,
                          enc_mlm_labels=None, dec_input_ids=torch.full((Bn, 1), 101, dtype=torch.long, device=device),
-                         dec_attention_mask=None, temperature=0.7, top_k=1, top_p=0.0, ngram_blocking_size=ngram, **kw).clone()
+                         dec_attention_mask=None, temperature=0.7, top_k=1, top_p=0.0, ngram_blocking_size=ngram,
+                         uniforms=uni[Bn], **kw).clone()
+
+    # the same uniforms for every call: bf16 logits TIE at the top now and then (8 mantissa bits over 30522 near-uniform values),
+    # top_k = 1 keeps every tied value like the reference's `logits < kth` filter does, and the draw among them follows the uniform
+    uni = {n: torch.rand(18, n, generator=torch.Generator().manual_seed(9)).clamp_min(1e-6).to(device) for n in (2, 16)}
 
     def plant(rows, s, k0=2):
         """tokens s[k0 .. k0+3] of every row -> the last four (padding) positions of its context, segment 0"""
