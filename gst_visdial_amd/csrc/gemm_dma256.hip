@@ -490,6 +490,149 @@ DEVFN void pc_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char*
       gemm_epilogue_tile<bf16, OT>(p, dk, acc[i][j], z, m0 + wm * WTM + i * 16 + li, n0 + wn * WTN + j * 16 + 4 * g);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Row-major A and B (the forward Linears with N >= 2304: QKV, FFN-up, cross-K/V, LM head), FULL-LINE staging (round 4).
+// The 32-deep stages above fetch 64 bytes of every operand row per K-step: half of a 128-byte line, whose other half is fetched
+// again one step later -- by then the 32 KB L1 has long turned over.  The LDS-DMA-only loop of such operands runs at 0.57 us per
+// 32 KB against 0.46 us for k-major operands, whose rows are whole lines (round 2), and the producer / consumer K-step is
+// producer bound.  Here an operand is filled 64 deep -- 128 bytes = one line per row and fill, 8 rows per wave instruction --
+// and the fills ALTERNATE: an odd 32-deep step issues A(j) (K range [64j, 64j+64), used in steps 2j, 2j+1; slot j % 3), an even
+// step B(j) (slot j % 2): still 32 KB of LDS-DMA per step, every byte of a fetched line used.  A(j) is issued in step 2j - 3 and
+// B(j) in step 2j - 2, i.e. three resp. two steps ahead of their first use; a slot is refilled two resp. one barrier after its
+// last read.  LDS: 3 x 32 KB + 2 x (32 | 24) KB.
+//   image of a fill: row r at 128 r, 16-byte slot s of the row at slot s ^ ((r >> 1) & 7) -- conflict-free for the b128 lane
+//   groups with the 16x16x32 fragment pattern (checked exhaustively); the swizzle is applied to the
+//   per-lane SOURCE address, the LDS side of the DMA stays lane-linear.
+// Requires K % 64 == 0 (every K of the step); other shapes take pc_tile256.
+// Measured (round 4, tools/r04_nt64_check.sh): K-step slope 0.702 -> 0.630 us at 4096 x 3072, 0.552 -> 0.498 at 4096 x 2304 (vendor
+// BLAS 0.495 / 0.399), fixed part +0.7 .. 1.0 us (three fills in front of the first MFMA); 4096x3072x768 30.4 -> 29.6 us.
+// An L2 PREFETCH of the lines of fill j + 2 .. 6 (consumer waves 0 / 1 touching this workgroup's share of the rows it shares with
+// the 8 resp. 4 workgroups of its XCD, one dword per line) changed nothing: slope 0.647 / 0.644 / 0.641 / 0.638 us for 0 / 2 / 4 / 6
+// fills ahead -- the ring is not waiting on beyond-L2 latency (removed again; tools/r04_nt64_pf.sh has the sweep).
+DEVFN int rm64_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
+
+template <int ROWS, int NP>            // NP = 1 KB pieces per producer wave and fill (ROWS / 32)
+struct Dma64 {
+  const char* ptr[NP];
+  bool okx[NP];
+  DEVFN void init(const char* g, int64_t ld, int64_t x0, int64_t X, int ptid) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int u = i * 256 + ptid, r = u >> 3, ls = (u & 7) ^ ((r >> 1) & 7);
+      const int64_t x = x0 + r;
+      okx[i] = x < X;
+      ptr[i] = g + (x * ld + ls * 8) * 2;
+    }
+  }
+  DEVFN void issue(int64_t j, int64_t J, char* img, int pw) const {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const char* src = (okx[i] && j < J) ? ptr[i] + j * 128 : (const char*)g_zero_page256;
+      glds16_asm(src, __builtin_amdgcn_readfirstlane(lds_addr(img + (i * 256 + pw * 64) * 16)));
+    }
+  }
+};
+
+template <typename OT, int NIU>
+DEVFN void pc_tile256_nt64(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char* smem) {
+  constexpr int BM = 256, WN = 4, WTM = 128, WTN = NIU * 16, MI = 8, NI = NIU, BNU = WN * WTN;
+  constexpr int A_SLOT = BM * 128, B_SLOT = BNU * 128, B_BASE = 3 * A_SLOT;
+  constexpr int NPA = BM / 32, NPB = BNU / 32;
+  static_assert(NPA + NPB <= 63, "vmcnt immediate out of range");
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntm = nwg / ntn;
+  const int SWD = g_strip_w;
+  const int strip = wg / (SWD * ntm), sw = (ntn - strip * SWD) < SWD ? (ntn - strip * SWD) : SWD;
+  const int within = wg - strip * SWD * ntm;
+  const int64_t m0 = (int64_t)(within / sw) * BM, n0 = (int64_t)(strip * SWD + within % sw) * BNU;
+  const int64_t nkt = p.K / 32, J = p.K / 64;
+
+  if (wave >= 8) {                     // ---- producers
+    const int ptid = tid - 512, pw = wave - 8;
+    Dma64<BM, NPA> ua;
+    Dma64<BNU, NPB> ub;
+    ua.init(p.A + z * p.sA * 2, p.lda, m0, p.M, ptid);
+    ub.init(p.B + z * p.sB * 2, p.ldb, n0, p.N, ptid);
+    ua.issue(0, J, smem, pw);
+    ub.issue(0, J, smem + B_BASE, pw);
+    ua.issue(1, J, smem + A_SLOT, pw);
+    int sa = 2, sb = 1;                // slots of the next A / B fill
+    int64_t ja = 2, jb = 1;
+    for (int64_t t = 0; t < nkt; t += 2) {
+      // even step t = 2j: A(j) and B(j) must have landed; the youngest fill in flight is A(j+1)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPA) : "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      ub.issue(jb, J, smem + B_BASE + sb * B_SLOT, pw);          // B(j+1): its slot held B(j-1), last read in step t - 1
+      ++jb; sb ^= 1;
+      // odd step: nothing new is needed (A(j), B(j) are in use); in flight: A(j+1), B(j+1)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPA + NPB) : "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      ua.issue(ja, J, smem + sa * A_SLOT, pw);                   // A(j+2): its slot held A(j-1), last read in step t - 1
+      ++ja; sa = (sa + 1 == 3) ? 0 : sa + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the trailing (zero page) fills
+    __builtin_amdgcn_s_barrier();                                 // pairs with the consumers' barrier in front of the epilogue
+    return;
+  }
+
+  const int wm = wave / WN, wn = wave % WN;                        // ---- consumers
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int sa = 0, sb = 0;
+  const int g = lane >> 4, li = lane & 15;
+  for (int64_t t = 0; t < nkt; t += 2) {
+    const char* cA = smem + sa * A_SLOT;
+    const char* cB = smem + B_BASE + sb * B_SLOT;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      bf16x8 fb[NI];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) fb[j] = *(const bf16x8*)(cB + rm64_off(wn * WTN + j * 16 + li, h * 4 + g));
+      if constexpr (NIU <= 3) {
+        bf16x8 fa[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) fa[i] = *(const bf16x8*)(cA + rm64_off(wm * WTM + i * 16 + li, h * 4 + g));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) acc[i][j] = mfma_bf16_k32(fb[j], fa[i], acc[i][j]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const bf16x8 fa = *(const bf16x8*)(cA + rm64_off(wm * WTM + i * 16 + li, h * 4 + g));
+#pragma unroll
+          for (int j = 0; j < NI; ++j) acc[i][j] = mfma_bf16_k32(fb[j], fa, acc[i][j]);
+        }
+      }
+    }
+    sa = (sa + 1 == 3) ? 0 : sa + 1;
+    sb ^= 1;
+  }
+  __builtin_amdgcn_s_barrier();        // every producer has drained its DMAs, every consumer is done with the ring: LDS is free
+  const DropKey dk = make_drop((p.epi & GSTVD_EPI_DROPOUT) ? p.p : 0.f, p.site, p.rng);
+  if constexpr (sizeof(OT) == 2) {
+    if (epilogue_rows_ok(p)) {
+      gemm_epilogue_rows<MI, NI, 4>(p, dk, acc, z, m0 + wm * WTM, n0 + wn * WTN, smem + wave * epi_wave_bytes<NI, 4>(), lane);
+      return;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+      gemm_epilogue_tile<bf16, OT>(p, dk, acc[i][j], z, m0 + wm * WTM + i * 16 + li, n0 + wn * WTN + j * 16 + 4 * g);
+}
+
 DEVFN int xcd_remap256(int bid, int nwg) {
   const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
@@ -506,6 +649,12 @@ template <typename OT, bool AKM, bool BKM, int NIU = 4>
 __global__ __launch_bounds__(768) void gemm_pc256_kernel(GemmP p, int ntn, int nwg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   pc_tile256<OT, AKM, BKM, NIU>(p, blockIdx.y, xcd_remap256(blockIdx.x, nwg), ntn, nwg, smem);
+}
+
+template <typename OT, int NIU>
+__global__ __launch_bounds__(768) void gemm_pc256_nt64_kernel(GemmP p, int ntn, int nwg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  pc_tile256_nt64<OT, NIU>(p, blockIdx.y, xcd_remap256(blockIdx.x, nwg), ntn, nwg, smem);
 }
 
 template <typename OT, bool AKM, bool BKM, int PF, int ST = 0>
@@ -572,6 +721,23 @@ static int launch256(const GemmP& p, int64_t batch, int niu, hipStream_t s) {
   // 0.76 us), +7 % on the 1368-tile cross-K/V projection (its extra ~1.5 us of fixed cost is paid 5.3 times): up to 2 rounds of tiles
   static const int pc = [] { const char* e = getenv("GSTVD_GEMM_PC"); return e ? atoi(e) : 1; }();
   if (pc && abl == 0 && st == 0 && (pc == 2 || (int64_t)ntm * ntn * batch <= 512)) {
+    if constexpr (!AKM && !BKM) {
+      // full-line (64-deep, alternating) staging of two row-major operands; GSTVD_GEMM_NT64=0 keeps the 32-deep stages (A/B)
+      static const int nt64 = [] { const char* e = getenv("GSTVD_GEMM_NT64"); return e ? atoi(e) : 1; }();
+      if (nt64 && p.K % 64 == 0 && p.K >= 128) {
+        auto n4 = gemm_pc256_nt64_kernel<OT, 4>;
+        auto n3 = gemm_pc256_nt64_kernel<OT, 3>;
+        constexpr int L4 = 3 * 256 * 128 + 2 * 256 * 128, L3 = 3 * 256 * 128 + 2 * 192 * 128;
+        constexpr int P4 = 8 * epi_wave_bytes<4, 4>(), P3 = 8 * epi_wave_bytes<3, 4>();
+        constexpr int lds4 = L4 > P4 ? L4 : P4, lds3 = L3 > P3 ? L3 : P3;
+        static_assert(lds4 <= 160 * 1024 && lds3 <= 160 * 1024, "LDS budget");
+        static int nt_rc = ensure_lds(n4, lds4) | ensure_lds(n3, lds3);
+        if (nt_rc) return nt_rc;
+        GSTVD_LAUNCH(bnu == 192 ? n3 : n4, dim3((unsigned)(ntm * ntn), (unsigned)batch), dim3(768), bnu == 192 ? lds3 : lds4, s, p, ntn, ntm * ntn);
+        GSTVD_LAUNCH_CHECK();
+        return 0;
+      }
+    }
     auto c4 = gemm_pc256_kernel<OT, AKM, BKM, 4>;
     auto c3 = gemm_pc256_kernel<OT, AKM, BKM, 3>;
     static int pc_rc = ensure_lds(c4, LDS256) | ensure_lds(c3, LDS256);
