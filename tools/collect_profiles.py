@@ -14,7 +14,9 @@ names = {"bench_n1.json": "bench_n1.json", "breakdown_events.json": "breakdown_e
          "slice_defaults_check.txt": "slice_defaults_check.txt", "gemm_vs_vendor_blas.txt": "gemm_vs_vendor_blas.txt",
          "row_split_probe.txt": "row_split_probe.txt", "grid_barrier.txt": "grid_barrier.txt",
          "kernel_trace_steps.csv.gz": "kernel_trace_steps.csv.gz", "launch_floor.txt": "launch_floor.txt",
-         "attention_study.txt": "attention_study.txt", "ring_depth_ab.txt": "ring_depth_ab.txt"}
+         "attention_study.txt": "attention_study.txt", "ring_depth_ab.txt": "ring_depth_ab.txt",
+         "bench_launch_paths.txt": "bench_launch_paths.txt", "bench_force_dist_legs.json": "bench_force_dist_legs.json",
+         "cold_operands.txt": "cold_operands.txt", "step_ab.txt": "step_ab.txt", "bench_wall.txt": "bench_wall.txt"}
 for a, b in names.items():
     p = os.path.join(src, a)
     if os.path.exists(p):
