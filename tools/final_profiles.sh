@@ -9,7 +9,7 @@ python3 -X faulthandler -m pytest tests/ -x -q -m gpu -p no:cacheprovider --dura
 python3 bench.py --breakdown-json $out/breakdown_events.json > $out/bench_stdout.log 2> $out/bench_stderr.log
 tail -1 $out/bench_stdout.log > $out/bench_n1.json
 # 3. rocprofv3 --stats of the same command (kernel averages must agree with roofline.avg_launch_us)
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-breakdown --no-fp32 --no-h2d > $out/prof_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-eval-decode --no-breakdown --no-fp32 --no-h2d > $out/prof_bench.log 2>&1
 cp $(ls $out/stats/*/*kernel_stats.csv | head -1) $out/kernel_stats_bench.csv; rm -rf $out/stats
 # 4. serialized per-(kernel, grid) durations
 bash tools/prof_serial.sh > $out/prof_serial.log 2>&1; cp gpurun_out/prof_serial/by_kernel_grid.json $out/serialized_by_kernel_grid.json
@@ -50,7 +50,7 @@ bash tools/row_split_probe.sh > $out/row_split_probe.txt 2>&1
 # 10e. (round 3) what bounds the step besides its FLOPs: the same graph at 2 rows x 32 tokens (launch-count floor) with its
 #      per-kernel durations and the host time of hipGraphLaunch; two concurrent chains of small GEMMs on real streams (no graph);
 #      attention kernels by batch rows / with dropout off + their SQ counters; ring depth A/B of the 128-tile GEMMs
-( echo "== bench.py at 2 rows x 32 tokens (same number of graph nodes)"; python3 bench.py --rows-per-gpu 2 --seq-len 32 --steps 30 --warmup 3 --no-cpu-baseline --no-fp32 --no-h2d --no-breakdown 2>/dev/null | tail -1 | cut -c1-200
+( echo "== bench.py at 2 rows x 32 tokens (same number of graph nodes)"; python3 bench.py --rows-per-gpu 2 --seq-len 32 --steps 30 --warmup 3 --no-cpu-baseline --no-eval-decode --no-fp32 --no-h2d --no-breakdown 2>/dev/null | tail -1 | cut -c1-200
   bash tools/trace_step.sh --rows-per-gpu 2 --seq-len 32 > /dev/null 2>&1; python3 tools/by_kernel.py
   echo "== hipGraphLaunch host time vs GPU span"; bash tools/launch_probe.sh 2 32 2>&1 | tail -5; bash tools/launch_probe.sh 16 256 2>&1 | tail -5
   echo "== two chains of dependent 400x768x768 GEMMs from a C++ loop (mode 0: one full-size chain; 1: two half-size chains on two streams; 2: the same on one stream)"
@@ -58,9 +58,9 @@ bash tools/row_split_probe.sh > $out/row_split_probe.txt 2>&1
 ( echo "== text self-attention 12 heads x 256 x 256 x 64 by batch rows"; for b in 1 4 8 16 32; do python3 tools/attn_probe.py $b 12 256 256 64 0 0.1 50 2>/dev/null | tail -1; done
   echo "== dropout off"; python3 tools/attn_probe.py 16 12 256 256 64 0 0.0 50 2>/dev/null | tail -1
   bash tools/pmc_attn.sh 2>&1 | grep -v amdgpu | tail -16 ) > $out/attention_study.txt 2>&1
-( for i in 1 2 3; do for ns in 5 3; do echo -n "GSTVD_GEMM128_NS=$ns: "; GSTVD_GEMM128_NS=$ns python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-fp32 --no-h2d --no-breakdown 2>/dev/null | tail -1 | cut -c60-100; done; done ) > $out/ring_depth_ab.txt 2>&1
+( for i in 1 2 3; do for ns in 5 3; do echo -n "GSTVD_GEMM128_NS=$ns: "; GSTVD_GEMM128_NS=$ns python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-eval-decode --no-fp32 --no-h2d --no-breakdown 2>/dev/null | tail -1 | cut -c60-100; done; done ) > $out/ring_depth_ab.txt 2>&1
 cut -c1-400 $out/bench_n1.json; tail -3 $out/gpu_tests_full.log; head -6 $out/kernel_stats_bench.csv | cut -c1-150
 # 11. the N>1 code path on one GPU (1-rank RCCL group: collectives, graded slices, bf16 payload, graph capture), both row counts
-for rows in 16 10; do GSTVD_FORCE_DIST=1 python3 bench.py --steps 10 --warmup 2 --rows-per-gpu $rows --grad-compress bf16 --no-cpu-baseline --no-breakdown --no-fp32 --no-h2d 2>/dev/null | tail -1 > $out/bench_force_dist_rows$rows.json; done
-python3 bench.py --steps 10 --warmup 2 --rows-per-gpu 10 --no-cpu-baseline --no-fp32 --no-h2d 2>/dev/null | tail -1 > $out/bench_n1_rows10.json
+for rows in 16 10; do GSTVD_FORCE_DIST=1 python3 bench.py --steps 10 --warmup 2 --rows-per-gpu $rows --grad-compress bf16 --no-cpu-baseline --no-eval-decode --no-breakdown --no-fp32 --no-h2d 2>/dev/null | tail -1 > $out/bench_force_dist_rows$rows.json; done
+python3 bench.py --steps 10 --warmup 2 --rows-per-gpu 10 --no-cpu-baseline --no-eval-decode --no-fp32 --no-h2d 2>/dev/null | tail -1 > $out/bench_n1_rows10.json
 cut -c1-300 $out/bench_force_dist_rows10.json

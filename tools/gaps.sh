@@ -2,7 +2,7 @@
 # Where does the main (text) queue wait?  Gap before every kernel of one replayed step on the busiest queue: histogram, and the
 # largest gaps with the kernels around them (what the queue was waiting for: the other stream, or just the dependent-launch gap).
 export TMPDIR=/tmp; out=gpurun_out/gaps; rm -rf $out; mkdir -p $out
-rocprofv3 --kernel-trace --output-format csv -d $out -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-breakdown --no-fp32 --no-h2d > $out/bench.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $out -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-eval-decode --no-breakdown --no-fp32 --no-h2d > $out/bench.log 2>&1
 python3 - <<'PY'
 import csv, glob, collections, re
 f = glob.glob('gpurun_out/gaps/*/*kernel_trace.csv')[0]

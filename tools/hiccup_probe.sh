@@ -2,7 +2,7 @@
 # Do the sporadic 100-400 us holes inside replayed steps (tools/trace_report.py lists them per step) coincide with the host's
 # hipGraphLaunch of the NEXT replay?  Kernel trace + HIP runtime API trace of the same run, correlated by timestamp.
 export TMPDIR=/tmp; out=gpurun_out/hiccup; rm -rf $out; mkdir -p $out
-rocprofv3 --kernel-trace --hip-runtime-trace --output-format csv -d $out -- python3 bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-breakdown --no-fp32 --no-h2d > $out/bench.log 2>&1
+rocprofv3 --kernel-trace --hip-runtime-trace --output-format csv -d $out -- python3 bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-eval-decode --no-breakdown --no-fp32 --no-h2d > $out/bench.log 2>&1
 ls $out/*/ | head
 python3 - <<'PY'
 import csv, glob, re

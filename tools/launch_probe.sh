@@ -2,7 +2,7 @@
 # host time of hipGraphLaunch vs GPU span of a step, at a shrunken workload (same node count)
 export TMPDIR=/tmp; out=gpurun_out/launchp; rm -rf $out; mkdir -p $out
 export GSTVD_ROW_SPLIT=0
-rocprofv3 --kernel-trace --hip-runtime-trace --output-format csv -d $out -- python3 bench.py --rows-per-gpu ${1:-2} --seq-len ${2:-32} --steps 12 --warmup 2 --no-cpu-baseline --no-breakdown --no-fp32 --no-h2d > $out/bench.log 2>&1
+rocprofv3 --kernel-trace --hip-runtime-trace --output-format csv -d $out -- python3 bench.py --rows-per-gpu ${1:-2} --seq-len ${2:-32} --steps 12 --warmup 2 --no-cpu-baseline --no-eval-decode --no-breakdown --no-fp32 --no-h2d > $out/bench.log 2>&1
 python3 - <<'PY'
 import csv, glob
 kt = glob.glob('gpurun_out/launchp/*/*kernel_trace.csv')[0]

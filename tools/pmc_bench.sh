@@ -2,7 +2,7 @@
 # HBM traffic of the dominant kernels inside the real train step (rocprofv3 PMC, one counter family per pass).
 export TMPDIR=/tmp; mkdir -p gpurun_out/pmc3
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc3/$c -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown --no-fp32 --no-h2d --graph off > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc3/$c -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-eval-decode --no-breakdown --no-fp32 --no-h2d --graph off > /dev/null 2>&1
 done
 python3 - <<'PY'
 import csv, glob, collections, json

@@ -2,7 +2,7 @@
 # Isolated per-kernel durations: every kernel of the step serialized on one stream (no overlap), rocprofv3 kernel trace,
 # aggregated by (kernel, grid size).
 export TMPDIR=/tmp; out=gpurun_out/prof_serial; rm -rf $out; mkdir -p $out
-rocprofv3 --kernel-trace --output-format csv -d $out -- python3 bench.py --steps 3 --warmup 1 --graph off --no-streams --no-pipeline --no-cpu-baseline --no-breakdown --no-fp32 --no-h2d > $out/bench.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $out -- python3 bench.py --steps 3 --warmup 1 --graph off --no-streams --no-pipeline --no-cpu-baseline --no-eval-decode --no-breakdown --no-fp32 --no-h2d > $out/bench.log 2>&1
 python3 - <<'PY'
 import csv, glob, collections, re, json
 f = glob.glob('gpurun_out/prof_serial/*/*kernel_trace.csv')[0]

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Per-stream timeline of one replayed step: where each HIP stream starts / ends, how busy it is, what runs last.
 export TMPDIR=/tmp; out=gpurun_out/timeline; rm -rf $out; mkdir -p $out
-rocprofv3 --kernel-trace --output-format csv -d $out -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-breakdown --no-fp32 --no-h2d > $out/bench.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $out -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-eval-decode --no-breakdown --no-fp32 --no-h2d > $out/bench.log 2>&1
 python3 - <<'PY'
 import csv, glob, collections, re
 f = glob.glob('gpurun_out/timeline/*/*kernel_trace.csv')[0]
