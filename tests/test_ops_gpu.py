@@ -104,6 +104,52 @@ def test_gemm_gelu_epilogues(dtype):
     check("dgelu", du, (da.float() @ w2.float()) * uref.grad, dtype)
 
 
+@pytest.mark.parametrize("case", [
+    # M, N, K, padded leading dimensions, epilogue, out dtype, batch -- all take the full-line (64-deep fill) NT 256-tile kernel
+    (4096, 3072, 768, 0, "gelu", torch.bfloat16, 1),      # FFN-up: 192-wide tiles, one per CU
+    (4096, 2304, 768, 0, "bias", torch.bfloat16, 1),      # QKV
+    (3000, 2824, 1024, 24, "add", torch.bfloat16, 1),     # ragged rows / columns, padded leading dimensions, K = 1024
+    (2048, 4096, 128, 0, "bias", torch.bfloat16, 1),      # two fills only (the prologue's), 256-wide tiles
+    (3000, 2824, 3072, 8, "none", torch.float32, 1),      # fp32 output: tile-wise epilogue; 48 fills
+    (1024, 1280, 192, 0, "bias", torch.bfloat16, 6),      # batched (120 tiles), K = 3 fills
+])
+def test_gemm_nt_full_line_tile(case):
+    """Round 4's pc_tile256_nt64 (row-major A and B, K % 64 == 0, 120..512 tiles): results against torch fp32 on every epilogue
+    / tail / stride combination the dispatcher can send it, and the library really dispatches these shapes to it."""
+    o = ops()
+    M, N, K, pad, epi, odt, Bn = case
+    bf = torch.bfloat16
+    x = rnd(Bn * M, K + pad, dtype=bf, seed=70)[:, :K]
+    w = rnd(Bn * N, K + pad, dtype=bf, seed=71, s=0.1)[:, :K]
+    b = rnd(N, seed=72)
+    y = torch.full((Bn * M, N + pad), float("nan"), device=DEV, dtype=odt)[:, :N]
+    kw = dict(lda=K + pad, ldb=K + pad, ldc=N + pad)
+    if Bn > 1:
+        kw.update(batch=Bn, sA=M * (K + pad), sB=N * (K + pad), sC=M * (N + pad))
+    xf, wf = x.float().view(Bn, M, K), w.float().view(Bn, N, K)
+    ref = torch.einsum("bmk,bnk->bmn", xf, wf)
+    aux = None
+    if epi == "bias":
+        o.gemm(x, w, y, M, N, K, bias=b, **kw); ref = ref + b
+    elif epi == "gelu":
+        aux = torch.empty(M, N, device=DEV, dtype=bf)
+        o.gemm(x, w, y, M, N, K, bias=b, aux=aux, epi=o.EPI_GELU, **kw)
+        u = (ref + b).requires_grad_(True)
+        g = torch.nn.functional.gelu(u); g.backward(torch.ones_like(g))
+        ref = g.detach()
+        check("nt64_gelu_deriv", aux, u.grad.view(M, N), bf)
+    elif epi == "add":
+        r = rnd(M, N + pad, dtype=bf, seed=73)[:, :N]
+        o.gemm(x, w, y, M, N, K, addend=r, ldadd=N + pad, **kw); ref = ref + r.float()
+    else:
+        o.gemm(x, w, y, M, N, K, **kw)
+    check("nt64", y.reshape(Bn, M, N) if pad == 0 else torch.stack([y[i * M:(i + 1) * M] for i in range(Bn)]), ref, bf)
+    with o.Profiler() as prof:                 # which device symbol did the library launch for this descriptor?
+        o.gemm(x, w, y, M, N, K, **kw)
+    launched = [k for k in prof.summary() if k.startswith("gemm:")]
+    assert len(launched) == 1 and "nt64" in launched[0], launched
+
+
 @pytest.mark.parametrize("lay", ["nt", "nn", "tn"])
 @pytest.mark.parametrize("shape", [(400, 768, 3072), (100, 200, 1992), (64, 64, 30528), (37, 132, 2304)])
 def test_gemm_splitk_matches_single_pass(lay, shape):
