@@ -508,7 +508,7 @@ DEVFN void pc_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char*
 // BLAS 0.495 / 0.399), fixed part +0.7 .. 1.0 us (three fills in front of the first MFMA); 4096x3072x768 30.4 -> 29.6 us.
 // An L2 PREFETCH of the lines of fill j + 2 .. 6 (consumer waves 0 / 1 touching this workgroup's share of the rows it shares with
 // the 8 resp. 4 workgroups of its XCD, one dword per line) changed nothing: slope 0.647 / 0.644 / 0.641 / 0.638 us for 0 / 2 / 4 / 6
-// fills ahead -- the ring is not waiting on beyond-L2 latency (removed again; tools/r04_nt64_pf.sh has the sweep).
+// fills ahead -- the ring is not waiting on beyond-L2 latency (removed again, with its sweep script).
 DEVFN int rm64_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
 
 template <int ROWS, int NP>            // NP = 1 KB pieces per producer wave and fill (ROWS / 32)
