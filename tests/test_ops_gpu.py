@@ -376,6 +376,8 @@ ATTN_CASES = [
     (1, 2, 130, 128, 64, False, -10000.0, 0.0, False),  # key count an exact multiple of the chunk
     (2, 2, 100, 100, 64, True, -10000.0, 0.1, True),    # causal across chunk boundaries
     (1, 4, 1, 200, 128, False, -1e9, 0.0, False),       # a single query (decode step shape)
+    (44, 12, 256, 256, 64, False, -10000.0, 0.1, True), # 34.6 M score elements = 17.3 M dropout draws: past 2^24, where the counter's
+                                                        # top byte used to drop out of the hash -- kernel masks == probe masks
 ]
 
 
