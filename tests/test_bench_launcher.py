@@ -98,3 +98,42 @@ def test_parse_last_json_and_rank_check():
     assert bench.check_rank_count(obj, 8) is not None
     assert bench.check_rank_count({"n_gpus": 1, "config": {"rccl": None}}, 1) is None
     assert bench.parse_last_json("{\"a\": 1}\ntrailing text")[0] is None
+
+
+def test_leg_children_get_a_clean_rank_environment_and_failures_stay_in_their_slot(monkeypatch):
+    """run_leg(): the child is `bench.py <args> <extra> --leg NAME` with RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* of its own and
+    WITHOUT the elastic agent's variables (TORCHELASTIC_USE_AGENT_STORE made the leg's rank 0 look for the parent launcher's store
+    on the leg's port: the rendezvous hung -- found in the one-GPU validation run); a failing or hanging child becomes
+    {"error": ...} for rank 0 and None elsewhere, never an exception."""
+    seen = {}
+
+    class R:
+        def __init__(self, rc, out):
+            self.returncode, self.stdout = rc, out
+
+    def fake_run(cmd, env=None, stdout=None, timeout=None):
+        seen.update(cmd=cmd, env=env, stdout=stdout, timeout=timeout)
+        return R(0, b'noise\n{"value": 5.0, "n_gpus": 2, "config": {"leg": "rows10"}}\n')
+
+    monkeypatch.setenv("TORCHELASTIC_USE_AGENT_STORE", "True")
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "abc")
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    res = bench.run_leg("rows10", ["--rows-per-gpu", "10"], ["--gpus", "2", "--steps", "3"], rank=0, world=2, local=0, port=29612)
+    assert res["value"] == 5.0
+    assert seen["cmd"][-4:] == ["--rows-per-gpu", "10", "--leg", "rows10"] and "--gpus" in seen["cmd"]
+    e = seen["env"]
+    assert not [k for k in e if k.startswith("TORCHELASTIC_")]
+    assert (e["RANK"], e["WORLD_SIZE"], e["LOCAL_RANK"], e["MASTER_ADDR"], e["MASTER_PORT"]) == ("0", "2", "0", "127.0.0.1", "29612")
+    assert seen["stdout"] == subprocess.PIPE
+    # a non-zero rank keeps its child's stdout off the shared terminal and reports nothing
+    assert bench.run_leg("rows10", [], [], rank=1, world=2, local=1, port=29612) is None and seen["stdout"] == subprocess.DEVNULL
+    # failures: exit code, missing line, timeout
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: R(3, b""))
+    assert "exit code 3" in bench.run_leg("x", [], [], 0, 2, 0, 1)["error"]
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: R(0, b"no json here\n"))
+    assert "no JSON" in bench.run_leg("x", [], [], 0, 2, 0, 1)["error"]
+
+    def hang(*a, **k):
+        raise subprocess.TimeoutExpired(cmd="bench.py", timeout=k.get("timeout"))
+    monkeypatch.setattr(subprocess, "run", hang)
+    assert "no result within" in bench.run_leg("x", [], [], 0, 2, 0, 1)["error"]
