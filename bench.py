@@ -441,11 +441,14 @@ def main():
         # (profiles/r03_chunk_sweep.txt); messages stay >= 44 MB (bf16), large enough for a point-to-point xGMI ring
         chunk_elems = [c << 20 for c in (22, 27, 27, 27, 27, 96, 96, 32, 16)]
     else:
-        # N = 1: the decoder's gradients are finished in small slices DURING its own latency-bound backward (the LM head first,
-        # then three decoder layers at a time: weight-gradient GEMMs + AdamW run beside a chain that leaves two thirds of the
-        # CUs idle), the encoder's in one large slice at the end (beside the encoder's throughput-bound backward smaller slices
-        # only move time around).  tools/chunk_sweep.sh, profiles/r03_chunk_sweep.txt: 13.87 vs 14.15-14.2 ms for [192, rest].
-        chunk_elems = [c << 20 for c in (22, 27, 27, 27, 27, 192)]
+        # N = 1: ONE slice after backward.  Its grouped weight-gradient launch applies AdamW to its weights in the tiles' epilogues
+        # (gstvd_gemm_grouped_adamw, pipeline.py `fuse_update`) -- the HBM-bound update streams under the other workgroups' K-loops
+        # -- and a short remainder pass covers biases / LayerNorm / embeddings: 12.82 ms against 13.23-13.30 ms for the two
+        # launches and 13.35-13.39 ms for round 3's list (22, 27, 27, 27, 27, 192 Mi: weight gradients + AdamW of the decoder's
+        # slices beside its backward chain), same box, profiles/r04_fuse_check.txt.  Slices during backward no longer pay at N = 1:
+        # beside the encoder's backward they only move time around, and a slice's AdamW takes the chip's wave slots from the
+        # decoder's chain (its next kernel waits for the whole update: tools/r04_bg_sweep.sh, profiles/r04_bg_sweep.txt).
+        chunk_elems = 1 << 40
     pipe = None if args.no_pipeline else BackwardPipeline(model.engine, optimizer=opt, chunk_elems=chunk_elems,
                                                           compress=compress, force_collective=force_dist)
 

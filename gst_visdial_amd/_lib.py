@@ -14,6 +14,7 @@ ABI_VERSION = 3
 F32, BF16 = 0, 1
 EPI_BIAS, EPI_ADD, EPI_GELU, EPI_DGELU, EPI_DROPOUT = 1, 2, 4, 8, 16
 EPI_COLSUM, EPI_COLSUM_ACC = 32, 64
+EPI_ADAMW = 128
 LN_RESID, LN_EMBED, LN_IMAGE = 0, 1, 2
 
 _vp, _i64, _i32, _f32, _u32 = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_uint32
@@ -58,6 +59,12 @@ class AttnDesc(C.Structure):
 class SampleDesc(C.Structure):
     _fields_ = [("logits", _vp), ("ld", _i64), ("dtype", _i32), ("B", _i32), ("V", _i32), ("top_k", _i32), ("temperature", _f32),
                 ("u", _vp), ("out", _vp), ("out_stride", _i64), ("banned", _vp), ("banned_ld", _i64)]
+
+
+class AdamFuse(C.Structure):
+    """gstvd_adamw_fuse_t: the flat buffers and constants of the optimizer, for the weight-gradient launch that updates in its epilogue."""
+    _fields_ = [("grad_base", _vp), ("param", _vp), ("m", _vp), ("v", _vp), ("shadow_bf16", _vp),
+                ("step", _vp), ("beta1", _f32), ("beta2", _f32), ("eps", _f32), ("grad_scale", _f32), ("write_grad", _i32)]
 
 
 class ColsumEntry(C.Structure):
@@ -108,6 +115,8 @@ SIGNATURES = {
     "gstvd_dropout_mask": (_i32, [_vp, _i64, _f32, _u32, _vp, _vp]),
     "gstvd_adamw": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _f32, _f32, _f32, _vp, _f32, _i64, _vp]),
     "gstvd_adamw_bf16grad": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _f32, _f32, _f32, _vp, _f32, _i64, _vp]),
+    "gstvd_adamw_blocks": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _f32, _f32, _f32, _vp, _f32, _i64, _vp, _i64, _vp, _vp]),
+    "gstvd_gemm_grouped_adamw": (_i32, [_vp, _vp, _i64, _i64, C.POINTER(AdamFuse), _vp]),
 }
 
 _STATUS = {-1: "GSTVD_E_DTYPE", -2: "GSTVD_E_SHAPE", -3: "GSTVD_E_ALIGN", -4: "GSTVD_E_NULL", -5: "GSTVD_E_UNSUPPORTED"}

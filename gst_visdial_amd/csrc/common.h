@@ -40,6 +40,36 @@ DEVFN void st4(bf16* p, f32x4 v) {
   *(bf16x4*)p = r;
 }
 
+// ---- AdamW, one 4-vector: pytorch_transformers==1.2.0 optimization.AdamW.step (train_gen.py:16,247) -----------------------
+// Shared by the stand-alone pass (loss.hip) and the weight-gradient launch that updates in its epilogue (gemm_dma256.hip): the
+// two must agree bit for bit, so contraction is OFF inside and every fused multiply-add is spelled out, and the update term
+// m / (sqrt(v) + eps) uses the hardware's 1-ulp v_sqrt_f32 / v_rcp_f32 in both (the IEEE sequences cost ~60 instructions per
+// element: invisible in the HBM-bound pass, ~30 us per tile in a GEMM epilogue with two waves per SIMD); the term is scaled by
+// lr before it meets the parameter, so its last ulp is ~1e-12 of the weight.
+// g = stored gradient (alpha * acc), gscale = 1/world; bc = sqrt(1 - b2^t) / (1 - b1^t); decay applied after the update.
+DEVFN void adamw_update4(f32x4& p4, f32x4& m4, f32x4& v4, f32x4 g4, float gscale, float lr, float wd, float bc, float b1, float b2,
+                         float eps) {
+#pragma clang fp contract(off)
+  const float step_size = lr * bc, decay = -lr * wd, c1 = 1.f - b1, c2 = 1.f - b2;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float g = g4[e] * gscale;
+    const float mm = __builtin_fmaf(m4[e], b1, g * c1);
+    const float vv = __builtin_fmaf(v4[e], b2, (g * g) * c2);
+    const float den = __builtin_amdgcn_sqrtf(vv) + eps;
+    float pp = __builtin_fmaf(-step_size, mm * __builtin_amdgcn_rcpf(den), p4[e]);
+    if (wd > 0.f) pp = __builtin_fmaf(decay, pp, pp);
+    m4[e] = mm; v4[e] = vv; p4[e] = pp;
+  }
+}
+DEVFN float adamw_bias_correction(float b1, float b2, float t) { return sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t)); }
+// first lr/wd segment whose (exclusive) end lies beyond flat index i: uniform arguments -> scalar loads
+DEVFN int64_t adamw_segment(const int64_t* seg_end, int64_t nseg, int64_t i) {
+  int64_t lo = 0, hi = nseg - 1;
+  while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (seg_end[mid] > i) hi = mid; else lo = mid + 1; }
+  return lo;
+}
+
 // ---- wave reductions (64 lanes) ----------------------------------------------------------------
 // Sum over the 64 lanes, result in every lane.  DPP moves inside the VALU (quad permutes, row mirrors, row broadcasts) instead
 // of six dependent ds_bpermute round trips through the LDS crossbar (~100 cycles each): the reductions sit on the critical

@@ -351,6 +351,59 @@ DEVFN void pp_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char*
       gemm_epilogue_tile<bf16, OT>(p, dk, acc[i][j], z, m0 + wm * WTM + i * 16 + li, n0 + wn * WTN + j * 16 + 4 * g);
 }
 
+// ---- weight-gradient tile whose epilogue IS the optimizer step (gstvd_gemm_grouped_adamw) --------------------------------------
+// The consumer waves hold 128 accumulator registers each and have nothing to spare for a stream of optimizer state (every
+// in-consumer form of this epilogue spilled 100+ registers per lane); the four PRODUCER waves are idle after the K-loop and own
+// nearly all of their 168 registers.  So: the consumers park their accumulators -- 4 x NI tiles = 64 rows at a time -- in their
+// slices of the idle ring, exactly as gemm_epilogue_rows does, and after a barrier each producer wave runs AdamW on the parked
+// rows of two consumer waves: a lane owns 4 consecutive columns of one row (16 lanes = one 256-byte row segment, whole lines per
+// instruction), 16-byte loads of param / m / v, the update of common.h, 16-byte stores of param / m / v and 8 bytes of bf16
+// shadow.  The state rows are fetched D row groups ahead of their use, IN PROGRAM ORDER in front of the stores of the groups in
+// between (the compiler may not move a load across a store it cannot tell apart from it): 3 D 16-byte loads in flight per lane.
+// Rows / columns outside the matrix: loads are clamped onto a valid element (no branch around a load), stores are masked.
+// Addresses: wave-uniform 64-bit bases + one 32-bit lane offset per row group.
+template <int NI, int ROWS, int D>
+DEVFN void adamw_rows_pass(const gstvd_adamw_fuse_t& af, float alpha, float lr, float wd, float bc, const float* park, int64_t flat0,
+                           int rows_left, int cols_left, unsigned ldc, int lane) {
+  static_assert(NI == 4, "16 lanes x 4 columns = the wave tile's 64 columns");
+  constexpr int S = epi_row_floats<NI>(), RPI = 4, R = ROWS / RPI;
+  if (rows_left <= 0 || cols_left <= 0) return;           // wave-uniform: the rows lie below / beside the matrix
+  const int rl = lane >> 4, c4 = (lane & 15) * 4;
+  const bool n_ok = c4 < cols_left;                       // N % 4 == 0: a 4-column piece is all in or all out
+  float* Pt = af.param + flat0; float* Mt = af.m + flat0; float* Vt = af.v + flat0;
+  bf16* St = (bf16*)af.shadow_bf16 + flat0;
+  float* Gt = const_cast<float*>(af.grad_base) + flat0;
+  const unsigned cofs = n_ok ? (unsigned)c4 : 0u;
+  const int last = rows_left - 1;
+  f32x4 bm[D + 1], bv[D + 1], bp[D + 1];
+  auto fetch = [&](int rr, int b) {
+    const int row = rr * RPI + rl;
+    const unsigned o = (unsigned)(row < last ? row : last) * ldc + cofs;
+    bm[b] = __builtin_nontemporal_load((const f32x4*)(Mt + o)); bv[b] = __builtin_nontemporal_load((const f32x4*)(Vt + o));
+    bp[b] = __builtin_nontemporal_load((const f32x4*)(Pt + o));
+  };
+#pragma unroll
+  for (int k = 0; k < D; ++k) fetch(k, k);
+#pragma unroll
+  for (int rr = 0; rr < R; ++rr) {
+    if (rr + D < R) fetch(rr + D, (rr + D) % (D + 1));
+    const int b = rr % (D + 1);
+    const int row = rr * RPI + rl;
+    f32x4 g4 = *(const f32x4*)(park + row * S + c4);
+    g4 = g4 * alpha;                                     // what the plain epilogue stores as dW
+    f32x4 p4 = bp[b], m4 = bm[b], v4 = bv[b];
+    adamw_update4(p4, m4, v4, g4, af.grad_scale, lr, wd, bc, af.beta1, af.beta2, af.eps);
+    if (row < rows_left && n_ok) {
+      const unsigned o = (unsigned)row * ldc + (unsigned)c4;
+      if (af.write_grad) st4(Gt + o, g4);
+      __builtin_nontemporal_store(m4, (f32x4*)(Mt + o));
+      __builtin_nontemporal_store(v4, (f32x4*)(Vt + o));
+      __builtin_nontemporal_store(p4, (f32x4*)(Pt + o));
+      if (af.shadow_bf16) st4(St + o, p4);
+    }
+  }
+}
+
 // Producer / consumer form of the same tile (GSTVD_GEMM_PC=1): 12 waves.  Waves 0-7 are the MFMA consumers of dma_tile256 (128x64 each)
 // and never touch the memory pipeline; waves 8-11 are LDS-DMA producers (8 pieces of 1 KB per wave and stage) and never touch
 // the matrix pipe.  One s_barrier per K-step still orders everything: before barrier t every producer has waited for its pieces
@@ -359,8 +412,8 @@ DEVFN void pp_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char*
 // issuing DMA and both waves of a SIMD do so at the same time (section 5 of DESIGN.md: 1358 cycles per step without any DMA
 // instruction, 1725 with); here the consumers' step IS that DMA-free loop and the DMA issue runs beside it on a third wave of
 // the SIMD.  Needs <= 168 VGPRs (three waves per SIMD).
-template <typename OT, bool AKM, bool BKM, int NIU = 4, bool CS = false>
-DEVFN void pc_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char* smem) {
+template <typename OT, bool AKM, bool BKM, int NIU = 4, bool CS = false, bool ADAM = false>
+DEVFN void pc_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char* smem, const gstvd_adamw_fuse_t af = gstvd_adamw_fuse_t{}) {
   constexpr int BM = 256, BN = 256, WN = 4, NS = NS256, NTP = 256;
   constexpr int WTM = 128, WTN = NIU * 16, MI = 8, NI = NIU, BNU = WN * WTN;
   constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;
@@ -437,6 +490,31 @@ DEVFN void pc_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char*
         }
       }
     }
+    if constexpr (ADAM) {
+      if (p.epi & GSTVD_EPI_ADAMW) {
+        // the tile's optimizer constants: uniform -> scalar loads.  addend = this weight's (lr, wd) pair in the device table
+        const float* hp2 = (const float*)p.addend;
+        const float ad_lr = hp2[0], ad_wd = hp2[1];
+        const float ad_bc = adamw_bias_correction(af.beta1, af.beta2, af.step[0]);
+        constexpr int HB = MI / 2, ROWS = HB * 16;
+        const int64_t cflat = (const float*)p.C - af.grad_base;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          __builtin_amdgcn_s_barrier();                    // the consumers have parked half h
+          if (ad_lr != 0.f) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {                  // this producer wave serves consumer waves 2 pw and 2 pw + 1
+              const int cw = pw * 2 + c, cwm = cw / WN, cwn = cw % WN;
+              const int64_t mw = m0 + cwm * WTM + h * ROWS, nw = n0 + cwn * WTN;
+              const int rows_left = (int)(p.M - mw < ROWS ? p.M - mw : ROWS), cols_left = (int)(p.N - nw < WTN ? p.N - nw : WTN);
+              adamw_rows_pass<NI, ROWS, 5>(af, p.alpha, ad_lr, ad_wd, ad_bc, (const float*)(smem + cw * epi_wave_bytes<NI, HB>()),
+                                           cflat + mw * p.ldc + nw, rows_left, cols_left, (unsigned)p.ldc, lane);
+            }
+          }
+          if (h == 0) __builtin_amdgcn_s_barrier();        // the parks may be overwritten
+        }
+      }
+    }
     return;
   }
 
@@ -476,6 +554,23 @@ DEVFN void pc_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char*
   }
   __builtin_amdgcn_s_barrier();       // every producer has drained its DMAs, every consumer is done with the ring: LDS is free
   const int g = lane >> 4, li = lane & 15;
+  if constexpr (ADAM) {
+    if (p.epi & GSTVD_EPI_ADAMW) {
+      // park 64 rows, let the producer waves update them (adamw_rows_pass), twice
+      constexpr int S = epi_row_floats<NI>(), HB = MI / 2;
+      float* park = (float*)(smem + wave * epi_wave_bytes<NI, HB>());
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (h) __builtin_amdgcn_s_barrier();              // the producers are done with the first half
+#pragma unroll
+        for (int i = 0; i < HB; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) *(f32x4*)(park + (i * 16 + li) * S + j * 16 + 4 * g) = acc[h * HB + i][j];
+        __builtin_amdgcn_s_barrier();                      // parked (a barrier waits for the wave's LDS writes)
+      }
+      return;
+    }
+  }
   const DropKey dk = make_drop((p.epi & GSTVD_EPI_DROPOUT) ? p.p : 0.f, p.site, p.rng);
   if constexpr (sizeof(OT) == 2) {
     if (epilogue_rows_ok(p)) {
@@ -808,6 +903,25 @@ __global__ __launch_bounds__(768) void gemm_pc256_grouped_kernel(const gstvd_gem
   pc_tile256<OT, AKM, BKM, 4, true>(p, 0, gid - tile_off[lo], ntn, ntm * ntn, smem);
 }
 
+__global__ __launch_bounds__(768) void gemm_pc256_grouped_adamw_kernel(const gstvd_gemm_t* tab, const int* tile_off, int nprob, int total, int chs,
+                                                                       gstvd_adamw_fuse_t af) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int full = total - total % (8 << chs), bid = blockIdx.x;
+  const int gid = bid < full ? (((bid >> 3) >> chs) * 8 + (bid & 7)) * (1 << chs) + ((bid >> 3) & ((1 << chs) - 1)) : bid;
+  int lo = 0, hi = nprob - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tile_off[mid] <= gid) lo = mid; else hi = mid - 1; }
+  const gstvd_gemm_t& g = tab[lo];
+  GemmP p;
+  p.A = (const char*)g.A; p.B = (const char*)g.B; p.C = (char*)g.C;
+  p.bias = g.bias; p.addend = (const char*)g.addend; p.aux = (char*)g.aux;
+  p.M = g.M; p.N = g.N; p.K = g.K;
+  p.lda = g.lda; p.ldb = g.ldb; p.ldc = g.ldc; p.ldadd = g.ldadd; p.ldaux = g.ldaux;
+  p.sA = p.sB = p.sC = p.sAdd = p.sAux = 0;
+  p.epi = g.epilogue; p.alpha = g.alpha; p.p = g.dropout_p; p.site = g.site; p.rng = g.rng;
+  const int ntn = (int)((g.N + 255) / 256), ntm = (int)((g.M + 255) / 256);
+  pc_tile256<float, true, true, 4, true, true>(p, 0, gid - tile_off[lo], ntn, ntm * ntn, smem, af);
+}
+
 template <typename OT, bool AKM, bool BKM>
 static int grouped256(const gstvd_gemm_t* tab, const int* off, int nprob, int total, hipStream_t s) {
   auto k0 = gemm_dma256_grouped_kernel<OT, AKM, BKM, 0>;
@@ -868,6 +982,22 @@ extern "C" int gstvd_debug_gemm_clock(uint64_t* out_host, int32_t n_words) {
   return e == hipSuccess ? 0 : (int)e;
 }
 #endif
+
+extern "C" int gstvd_gemm_grouped_adamw(const gstvd_gemm_t* table_dev, const int32_t* tile_off_dev, int64_t nprob, int64_t total_tiles,
+                                        const gstvd_adamw_fuse_t* f, gstvd_stream_t stream) {
+  if (!table_dev || !tile_off_dev || !f) return GSTVD_E_NULL;
+  if (!f->grad_base || !f->param || !f->m || !f->v || !f->step) return GSTVD_E_NULL;
+  if (nprob <= 0 || total_tiles <= 0) return GSTVD_E_SHAPE;
+  if (((uintptr_t)f->grad_base | (uintptr_t)f->param | (uintptr_t)f->m | (uintptr_t)f->v | (uintptr_t)f->shadow_bf16) & 15) return GSTVD_E_ALIGN;
+  if (!(gstvd_gemm_group_caps() & 1)) return GSTVD_E_UNSUPPORTED;     // the producer / consumer tile is switched off (tuning runs)
+  auto kp = gemm_pc256_grouped_adamw_kernel;
+  static int rc = ensure_lds(kp, LDS256);
+  if (rc) return rc;
+  static const int chs = [] { const char* e = getenv("GSTVD_GROUP_CHUNK_LOG2"); const int v = e ? atoi(e) : 3; return v < 0 ? 0 : (v > 10 ? 10 : v); }();
+  GSTVD_LAUNCH(kp, dim3((unsigned)total_tiles), dim3(768), LDS256, (hipStream_t)stream, table_dev, tile_off_dev, (int)nprob, (int)total_tiles, chs, *f);
+  GSTVD_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int gstvd_gemm_grouped(const gstvd_gemm_t* table_dev, const int32_t* tile_off_dev, int64_t nprob, int64_t total_tiles,
                                   int32_t dtype_in, int32_t dtype_out, int32_t a_kmajor, int32_t b_kmajor, gstvd_stream_t stream) {

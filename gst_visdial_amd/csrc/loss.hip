@@ -126,15 +126,14 @@ __global__ void dropout_mask_kernel(float* out, int64_t n, float p, uint32_t sit
 template <typename GT>
 __global__ __launch_bounds__(256) void adamw_kernel(float* param, const GT* grad, float* m, float* v, bf16* shadow, int64_t n,
                                                     const int64_t* seg_end, const float* hp, int64_t nseg, float b1, float b2,
-                                                    float eps, const float* step, float gscale, int64_t base, int64_t gorigin) {
-  // the launch covers flat elements [base, n) of the buffers (pointers are the buffers' starts); segment ends are absolute
+                                                    float eps, const float* step, float gscale, int64_t base, int64_t gorigin,
+                                                    const int32_t* blocks, const uint8_t* seg_skip) {
+  // the launch covers flat elements [base, n) of the buffers (pointers are the buffers' starts), or -- `blocks` given -- the
+  // listed 1024-element blocks; segment ends are absolute
   __shared__ float s_bc;
-  const int64_t i0 = base + (int64_t)blockIdx.x * 1024;           // block-uniform: the search below runs on scalar loads
+  const int64_t i0 = blocks ? (int64_t)blocks[blockIdx.x] * 1024 : base + (int64_t)blockIdx.x * 1024;   // block-uniform: scalar loads below
   const int64_t i = i0 + threadIdx.x * 4;
-  if (threadIdx.x == 0) {
-    const float t = step[0];
-    s_bc = sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));         // bias correction, once per block
-  }
+  if (threadIdx.x == 0) s_bc = adamw_bias_correction(b1, b2, step[0]);     // once per block
   // streaming operands first (their latency overlaps the segment lookup); nothing here is re-read, keep it out of L2's way
   const bool vec = i + 3 < n;
   f32x4 g4 = {0.f, 0.f, 0.f, 0.f}, m4 = g4, v4 = g4, p4 = g4;
@@ -144,24 +143,15 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* param, const GT* grad
     v4 = __builtin_nontemporal_load((const f32x4*)(v + i));
     p4 = __builtin_nontemporal_load((const f32x4*)(param + i));
   }
-  int64_t lo = 0, hi = nseg - 1;                       // first segment whose end > i0
-  while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (seg_end[mid] > i0) hi = mid; else lo = mid + 1; }
+  int64_t lo = adamw_segment(seg_end, nseg, i0);        // first segment whose end > i0
   __syncthreads();
-  if (i >= n) return;
+  if (i >= n || i < base) return;                    // (i < base: only with a block list, whose blocks may straddle the range's start)
   while (lo < nseg - 1 && seg_end[lo] <= i) ++lo;     // at most a few steps inside a 1024-element block
   const float lr = hp[2 * lo], wd = hp[2 * lo + 1];
   const float bc = s_bc;
   if (vec && seg_end[lo] >= i + 4) {
-    if (lr == 0.f) return;                               // padding / frozen segment
-    g4 *= gscale;
-    m4 = m4 * b1 + g4 * (1.f - b1);
-    v4 = v4 * b2 + g4 * g4 * (1.f - b2);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float pp = p4[e] - lr * bc * (m4[e] / (sqrtf(v4[e]) + eps));
-      if (wd > 0.f) pp += -lr * wd * pp;
-      p4[e] = pp;
-    }
+    if (lr == 0.f || (seg_skip && seg_skip[lo])) return;   // padding / frozen segment / updated by the weight-gradient launch
+    adamw_update4(p4, m4, v4, g4, gscale, lr, wd, bc, b1, b2, eps);
     __builtin_nontemporal_store(m4, (f32x4*)(m + i));
     __builtin_nontemporal_store(v4, (f32x4*)(v + i));
     __builtin_nontemporal_store(p4, (f32x4*)(param + i));
@@ -173,14 +163,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* param, const GT* grad
     const int64_t k = i + e;
     while (seg < nseg - 1 && seg_end[seg] <= k) ++seg;
     const float lr_ = hp[2 * seg], wd_ = hp[2 * seg + 1];
-    const float gg = (float)grad[k - gorigin] * gscale;
-    const float mm = m[k] * b1 + (1.f - b1) * gg;
-    const float vv = v[k] * b2 + (1.f - b2) * gg * gg;
-    m[k] = mm; v[k] = vv;
-    float pp = param[k] - lr_ * bc * (mm / (sqrtf(vv) + eps));
-    if (wd_ > 0.f) pp += -lr_ * wd_ * pp;
-    param[k] = pp;
-    if (shadow) shadow[k] = (bf16)pp;
+    if (lr_ == 0.f || (seg_skip && seg_skip[seg])) continue;
+    f32x4 g1 = {(float)grad[k - gorigin], 0.f, 0.f, 0.f}, m1 = {m[k], 0.f, 0.f, 0.f}, v1 = {v[k], 0.f, 0.f, 0.f}, p1 = {param[k], 0.f, 0.f, 0.f};
+    adamw_update4(p1, m1, v1, g1, gscale, lr_, wd_, bc, b1, b2, eps);
+    m[k] = m1[0]; v[k] = v1[0]; param[k] = p1[0];
+    if (shadow) shadow[k] = (bf16)p1[0];
   }
 }
 
@@ -297,7 +284,8 @@ extern "C" int gstvd_adamw(float* param, const float* grad, float* m, float* v, 
   if (!param || !grad || !m || !v || !seg_end || !hp || !step) return GSTVD_E_NULL;
   if (n <= 0 || nseg <= 0 || begin < 0 || begin >= n || (begin % 4)) return GSTVD_E_SHAPE;
   hipLaunchKernelGGL(adamw_kernel<float>, dim3((unsigned)((n - begin + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, param, grad,
-                     m, v, (bf16*)shadow_bf16, n, seg_end, hp, nseg, beta1, beta2, eps, step, grad_scale, begin, (int64_t)0);
+                     m, v, (bf16*)shadow_bf16, n, seg_end, hp, nseg, beta1, beta2, eps, step, grad_scale, begin, (int64_t)0,
+                     (const int32_t*)nullptr, (const uint8_t*)nullptr);
   GSTVD_LAUNCH_CHECK();
   return 0;
 }
@@ -310,7 +298,21 @@ extern "C" int gstvd_adamw_bf16grad(float* param, const void* grad_bf16, int64_t
   if ((uintptr_t)grad_bf16 & 7) return GSTVD_E_ALIGN;
   hipLaunchKernelGGL(adamw_kernel<bf16>, dim3((unsigned)((n - begin + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, param,
                      (const bf16*)grad_bf16, m, v, (bf16*)shadow_bf16, n, seg_end, hp, nseg, beta1, beta2, eps, step, grad_scale, begin,
-                     grad_origin);
+                     grad_origin, (const int32_t*)nullptr, (const uint8_t*)nullptr);
+  GSTVD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gstvd_adamw_blocks(float* param, const float* grad, float* m, float* v, void* shadow_bf16, int64_t n,
+                                  const int64_t* seg_end, const float* hp, int64_t nseg, float beta1, float beta2, float eps,
+                                  const float* step, float grad_scale, int64_t begin, const int32_t* block_list_dev, int64_t nblocks,
+                                  const uint8_t* seg_skip_dev, gstvd_stream_t stream) {
+  if (!param || !grad || !m || !v || !seg_end || !hp || !step || !block_list_dev) return GSTVD_E_NULL;
+  if (n <= 0 || nseg <= 0 || begin < 0 || begin >= n || (begin % 4) || nblocks < 0 || nblocks > (n + 1023) / 1024) return GSTVD_E_SHAPE;
+  if (nblocks == 0) return 0;
+  hipLaunchKernelGGL(adamw_kernel<float>, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, param, grad, m, v,
+                     (bf16*)shadow_bf16, n, seg_end, hp, nseg, beta1, beta2, eps, step, grad_scale, begin, (int64_t)0,
+                     block_list_dev, seg_skip_dev);
   GSTVD_LAUNCH_CHECK();
   return 0;
 }

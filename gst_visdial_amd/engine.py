@@ -451,18 +451,18 @@ class Engine(object):
             # j+1, also with the weight-gradient launch confined to 160-224 CUs: 13.73-14.01 ms against 13.72 ms, resp. +0.3 ms --
             # the two full-chip kernels do not share the chip profitably; profiles/r03_chunk_sweep.txt.  Not kept.)
             with torch.cuda.stream(self.aux):
-                self.wgrads.flush()
+                fused = self.wgrads.flush(fuse=self.pipe.fuse_handle())
             self.colsums.flush()
             ev = torch.cuda.Event()
             ev.record(self.main)
             self.aux.wait_event(ev)
             with torch.cuda.stream(self.aux):
-                self.pipe.run_slice(off, self.pipe.hi)
+                self.pipe.run_slice(off, self.pipe.hi, fused=fused)
         else:
             with torch.cuda.stream(self.aux):
-                self.wgrads.flush()
+                fused = self.wgrads.flush(fuse=self.pipe.fuse_handle())
                 self.colsums.flush()
-                self.pipe.run_slice(off, self.pipe.hi)
+                self.pipe.run_slice(off, self.pipe.hi, fused=fused)
         self.aux_busy = True
 
     # -- two HIP streams: the vision stream's skinny (M = B*37) kernels run beside the text stream's --------------

@@ -254,13 +254,32 @@ class GemmGroup(object):
     def reset(self):
         self.items, self.keep = [], []
 
-    def flush(self):
+    def flush(self, fuse=None):
+        """Launch the queued problems.  `fuse` (optim.FusedAdamW.fuse_handle(), single-GPU training only): every queued weight
+        gradient that is the ONLY contribution to its weight this step gets GSTVD_EPI_ADAMW -- the launch updates the weight in
+        its epilogue (gstvd_gemm_grouped_adamw) instead of storing dW.  Returns the flat offsets of the weights updated that way
+        (a tuple, empty without fusion): the caller's remainder pass must leave them alone."""
         if not self.items:
-            return
+            return ()
         keep, self.keep = self.keep, []      # released when this call returns (after the launch is enqueued)
+        fused = ()
+        if fuse is not None and self.dtype_in == BF16 and self.dtype_out == F32 and self.a_km and self.b_km:
+            items, fl = [], []
+            for it in self.items:
+                (a, b, c, M, N, K, lda, ldb, ldc, acc, cs_ptr, cs_acc) = it[:12]
+                hp_addr = 0 if acc else fuse.hp_addr(c, M, N, ldc)
+                if hp_addr:
+                    fl.append(fuse.flat_offset(c))
+                items.append(it[:12] + (hp_addr,))
+            if fl:
+                self.items, fused = items, tuple(fl)
+            else:
+                fuse = None
+        else:
+            fuse = None
         if self.dtype_in != BF16:            # fp32 parity mode: plain launches
             lib = L.load()
-            for (a, b, c, M, N, K, lda, ldb, ldc, acc, cs_ptr, cs_acc) in self.items:
+            for (a, b, c, M, N, K, lda, ldb, ldc, acc, cs_ptr, cs_acc) in [it[:12] for it in self.items]:
                 if cs_ptr:
                     raise L.GstvdError("column sums ride on the grouped bf16 launch only")
                 d = L.GemmDesc()
@@ -270,7 +289,7 @@ class GemmGroup(object):
                     d.addend, d.ldadd, d.epilogue = c, ldc, EPI_ADD
                 L.check("gstvd_gemm", lib.gstvd_gemm(C.byref(d), _stream()))
             self.items = []
-            return
+            return ()
         key = tuple(self.items)
         hit = self.cache.get(key)
         if hit is None:
@@ -278,18 +297,24 @@ class GemmGroup(object):
             offs, tiles, flops, nbytes = [], 0, 0.0, 0.0
             esz_in, esz_out = (2 if self.dtype_in == BF16 else 4), (2 if self.dtype_out == BF16 else 4)
             T = int(L.load().gstvd_gemm_group_tile())
-            for d, (a, b, c, M, N, K, lda, ldb, ldc, acc, cs_ptr, cs_acc) in zip(arr, key):
+            for d, it in zip(arr, key):
+                (a, b, c, M, N, K, lda, ldb, ldc, acc, cs_ptr, cs_acc) = it[:12]
                 d.A, d.B, d.C, d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.batch = a, b, c, M, N, K, lda, ldb, ldc, 1
                 d.dtype_in, d.dtype_out, d.a_kmajor, d.b_kmajor, d.alpha = self.dtype_in, self.dtype_out, int(self.a_km), int(self.b_km), 1.0
                 if acc:
                     d.addend, d.ldadd, d.epilogue = c, ldc, EPI_ADD
+                elif len(it) > 12 and it[12]:   # the weight's (lr, wd) pair: updated in the launch's epilogue
+                    d.addend, d.epilogue = it[12], L.EPI_ADAMW
                 if cs_ptr:                      # bias[m] (+)= sum_k A[k][m] out of the same launch
                     d.bias = cs_ptr
                     d.epilogue |= L.EPI_COLSUM | (L.EPI_COLSUM_ACC if cs_acc else 0)
                 offs.append(tiles)
                 tiles += ((M + T - 1) // T) * ((N + T - 1) // T)
                 flops += 2.0 * M * N * K
-                nbytes += esz_in * (M * K + K * N) + esz_out * M * N * (2 if acc else 1)
+                if len(it) > 12 and it[12]:
+                    nbytes += esz_in * (M * K + K * N) + M * N * 26.0       # param / m / v in and out + bf16 shadow, no dW
+                else:
+                    nbytes += esz_in * (M * K + K * N) + esz_out * M * N * (2 if acc else 1)
             tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
             off = torch.tensor(offs, dtype=torch.int32).to(self.device)
             hit = (tab, off, len(key), tiles, flops, nbytes)
@@ -299,6 +324,13 @@ class GemmGroup(object):
         tab, off, n, tiles, flops, nbytes = hit
         lib = L.load()
         e0 = _prof_begin()
+        if fuse is not None:
+            L.check("gstvd_gemm_grouped_adamw", lib.gstvd_gemm_grouped_adamw(tab.data_ptr(), off.data_ptr(), n, tiles, C.byref(fuse.desc()),
+                                                                             _stream()))
+            if e0 is not None:
+                _prof_end(e0, "gemm:gemm_pc256_grouped_adamw_kernel", flops, nbytes, (n, tiles))
+            self.items = []
+            return fused
         L.check("gstvd_gemm_grouped", lib.gstvd_gemm_grouped(tab.data_ptr(), off.data_ptr(), n, tiles, self.dtype_in, self.dtype_out,
                                                              int(self.a_km), int(self.b_km), _stream()))
         if e0 is not None:
@@ -311,6 +343,7 @@ class GemmGroup(object):
                 name = _KNAME[key] = buf.value.decode()
             _prof_end(e0, "gemm:" + name, flops, nbytes, (n, tiles))
         self.items = []
+        return ()
 
 
 def _ln_desc(mode, dtype, M, H, gamma, beta, mean, rstd, eps, x=None, res=None, y=None, p_pre=0.0, p_post=0.0,
@@ -597,6 +630,20 @@ def adamw(param, grad, m, v, shadow, seg_end, hp, step, beta1=0.9, beta2=0.999, 
         L.check("gstvd_adamw", lib.gstvd_adamw(_p(param), _p(grad), _p(m), _p(v), _p(shadow), n, _p(seg_end), _p(hp),
                                                seg_end.numel(), beta1, beta2, eps, _p(step), grad_scale, begin, _stream()))
     _prof_end(e0, "adamw", 0.0, (n - begin) * (30.0 if shadow is not None else 28.0))
+
+
+def adamw_blocks(param, grad, m, v, shadow, seg_end, hp, step, blocks, seg_skip, beta1=0.9, beta2=0.999, eps=1e-6, grad_scale=1.0,
+                 begin=0, end=None):
+    """AdamW on the listed 1024-element blocks (int32 device tensor of absolute block indices), clipped to [begin, end), leaving
+    the segments flagged in `seg_skip` (uint8 device tensor, one per segment) alone: the remainder behind a weight-gradient
+    launch that updated its weights itself (GemmGroup.flush(fuse=...))."""
+    lib = L.load()
+    n = param.numel() if end is None else end
+    e0 = _prof_begin()
+    L.check("gstvd_adamw_blocks", lib.gstvd_adamw_blocks(_p(param), _p(grad), _p(m), _p(v), _p(shadow), n, _p(seg_end), _p(hp),
+                                                         seg_end.numel(), beta1, beta2, eps, _p(step), grad_scale, begin, _p(blocks),
+                                                         blocks.numel(), _p(seg_skip), _stream()))
+    _prof_end(e0, "adamw", 0.0, blocks.numel() * 1024 * (30.0 if shadow is not None else 28.0))
 
 
 def gemm_ln_rows():

@@ -46,6 +46,39 @@ def reference_param_index(model):
     return out
 
 
+class _FuseHandle(object):
+    """See FusedAdamW.fuse_handle()."""
+
+    def __init__(self, opt, write_grad):
+        from . import _lib as L
+        self.opt, self.write_grad = opt, write_grad
+        flat = opt.engine.flat
+        d = L.AdamFuse()
+        d.grad_base, d.param, d.m, d.v = flat.G.data_ptr(), flat.P.data_ptr(), opt.m.data_ptr(), opt.v.data_ptr()
+        d.shadow_bf16 = flat.S.data_ptr() if flat.S is not None else None
+        d.step, d.beta1, d.beta2, d.eps = opt.step_dev.data_ptr(), opt.betas[0], opt.betas[1], opt.eps
+        d.write_grad = int(write_grad)
+        self._desc, self._g0, self._n = d, flat.G.data_ptr(), flat.G.numel()
+
+    def desc(self):
+        self._desc.grad_scale = self.opt.grad_scale
+        return self._desc
+
+    def flat_offset(self, c_ptr):
+        return (c_ptr - self._g0) // 4
+
+    def hp_addr(self, c_ptr, M, N, ldc):
+        """Device address of the (lr, wd) pair of the weight whose gradient slot starts at c_ptr, or 0 when the launch must not
+        update it: not a whole contiguous tensor of the flat buffer, or frozen."""
+        off = c_ptr - self._g0
+        if off < 0 or off % 16 or ldc != N or N % 4:
+            return 0
+        seg = self.opt.seg_of.get(off // 4)
+        if seg is None or seg[1] != M * N or not self.opt.base[seg[0]][2]:
+            return 0
+        return self.opt.hp.data_ptr() + 8 * seg[0]
+
+
 class FusedAdamW(object):
     def __init__(self, model, lr=2e-5, image_lr=None, language_weights=None, weight_decay=0.01, betas=(0.9, 0.999),
                  eps=1e-6, warmup_steps=0, t_total=0, min_lr=1e-5, train_vlfusion=False):
@@ -82,7 +115,7 @@ class FusedAdamW(object):
         flat = self.engine.flat
         dev = flat.P.device
         names = self._names()
-        ends, base = [], []
+        ends, base, seg_of = [], [], {}
         prev = 0
         for p, off in flat.items:
             if off > prev:                       # alignment gap / zero padding: lr 0 keeps it untouched
@@ -91,11 +124,14 @@ class FusedAdamW(object):
             lr = self.lr if (self.language_weights is None or n in self.language_weights) else self.image_lr
             wd = 0.0 if any(nd in n for nd in NO_DECAY) else self.weight_decay
             frozen = n.startswith("vlfusion.") and not self.train_vlfusion
+            seg_of[off] = (len(ends), p.numel())
             ends.append(off + p.numel()); base.append((0.0, 0.0, 0.0) if frozen else (lr, wd, 1.0))
             prev = off + p.numel()
         if prev < flat.n_live:
             ends.append(flat.n_live); base.append((0.0, 0.0, 0.0))
         self.seg_end = torch.tensor(ends, dtype=torch.int64, device=dev)
+        self.seg_ends_host, self.seg_of = ends, seg_of      # flat offset of a tensor -> (segment index, numel)
+        self._fuse, self._remainders = None, {}
         self.base = base
         self.hp_host = torch.empty(len(base) * 2, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.empty(len(base) * 2)
         self.hp = torch.empty(len(base) * 2, dtype=torch.float32, device=dev)
@@ -161,11 +197,20 @@ class FusedAdamW(object):
         self.opt_step += 1
         self.step_dev.add_(1.0)
 
-    def apply_range(self, lo, hi, grad_bf16=None):
+    def apply_range(self, lo, hi, grad_bf16=None, fused=()):
         """AdamW on flat elements [lo, hi) -- used slice by slice by the backward pipeline.  `grad_bf16`: the slice's
-        gradients as a bf16 tensor of hi-lo elements (the all-reduced compressed copy) instead of G[lo:hi]."""
+        gradients as a bf16 tensor of hi-lo elements (the all-reduced compressed copy) instead of G[lo:hi].  `fused`: flat
+        offsets of the weights the slice's weight-gradient launch has already updated (ops.GemmGroup.flush(fuse=...)): only the
+        1024-element blocks that hold anything else are visited, and those weights' segments are skipped inside them."""
         flat = self.engine.flat
-        if grad_bf16 is not None:
+        if fused:
+            if grad_bf16 is not None:
+                raise ValueError("a fused weight-gradient update and a compressed gradient slice exclude each other")
+            blocks, skip = self._remainder(lo, hi, fused)
+            if blocks.numel():
+                ops.adamw_blocks(flat.P, flat.G, self.m, self.v, flat.S, self.seg_end, self.hp, self.step_dev, blocks, skip,
+                                 self.betas[0], self.betas[1], self.eps, self.grad_scale, begin=lo, end=hi)
+        elif grad_bf16 is not None:
             ops.adamw(flat.P, grad_bf16, self.m, self.v, flat.S, self.seg_end, self.hp, self.step_dev, self.betas[0],
                       self.betas[1], self.eps, self.grad_scale, begin=lo, end=hi, grad_origin=lo)
         else:
@@ -173,6 +218,45 @@ class FusedAdamW(object):
                       self.betas[1], self.eps, self.grad_scale, begin=lo, end=hi)
         if flat.S is not None:
             flat.shadow_version = flat.version()
+
+    def _remainder(self, lo, hi, fused):
+        """(block list, segment skip flags) of apply_range(lo, hi, fused=...), cached per (lo, hi, fused) -- built once, before any
+        hipGraph capture (the eager warm-up steps run the same slices)."""
+        key = (lo, hi, fused)
+        hit = self._remainders.get(key)
+        if hit is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("FusedAdamW: new slice / fusion pattern during a hipGraph capture -- run one eager step first")
+            dev = self.seg_end.device
+            fused_segs = set(self.seg_of[o][0] for o in fused)
+            skip = torch.zeros(len(self.seg_ends_host), dtype=torch.uint8)
+            need = set()
+            start = 0
+            for i, end in enumerate(self.seg_ends_host):
+                a, b = max(start, lo), min(end, hi)
+                start = end
+                if i in fused_segs:
+                    skip[i] = 1
+                    continue
+                if b <= a or not self.base[i][2]:          # outside the slice / padding or frozen (lr 0)
+                    continue
+                need.update(range(a // 1024, (b - 1) // 1024 + 1))
+            blocks = torch.tensor(sorted(need), dtype=torch.int32)
+            hit = (blocks.to(dev), skip.to(dev))
+            if len(self._remainders) > 64:
+                self._remainders.clear()
+            self._remainders[key] = hit
+        return hit
+
+    def fuse_handle(self, write_grad=False):
+        """What ops.GemmGroup.flush(fuse=...) needs to let the weight-gradient launch run this optimizer's update in its epilogue
+        (single GPU, gradients not accumulated over several backward passes): the flat buffers + constants, and the device address
+        of a weight's (lr, wd) pair.  None until the optimizer state exists."""
+        if not self._ensure_built():
+            return None
+        if self._fuse is None or self._fuse.write_grad != bool(write_grad):
+            self._fuse = _FuseHandle(self, bool(write_grad))
+        return self._fuse
 
     def step(self):
         """optimizer.step(): one fused launch over the flat buffers -- or nothing, when a BackwardPipeline already

@@ -44,6 +44,11 @@ class BackwardPipeline(object):
         # (MFMA-bound) and the rest of backward.  Zero-sum with round 2's two large slices; with the decoder's gradients finished
         # in small slices during its own backward it is worth 0.35 ms per step (tools/chunk_sweep.sh: 13.65 vs 14.00 ms)
         self.update_stream = os.environ.get("GSTVD_PIPE_UPDATE_STREAM", "1") != "0"
+        # N = 1: nothing stands between a weight gradient and its update, so the grouped weight-gradient launch applies AdamW in
+        # its epilogue (gstvd_gemm_grouped_adamw: 26 bytes per weight instead of 4 + 30, streamed by the tile's idle producer
+        # waves under the other workgroups' K-loops) and the AdamW pass shrinks to the ~5 % of the parameters that are not GEMM
+        # weights.  Bit-identical to the two launches.  With keep_grads the launch also stores dW for `.grad`.
+        self.fuse_update = os.environ.get("GSTVD_FUSE_UPDATE", "1") != "0"
         if optimizer is not None:
             optimizer.grad_scale = 1.0 / self.world
         engine.pipe = self
@@ -55,6 +60,12 @@ class BackwardPipeline(object):
         if self.opt is not None:
             self.opt.begin_step()
 
+    def fuse_handle(self):
+        """Not None when the slice's weight-gradient launch may update its weights itself (see __init__)."""
+        if self.collective or self.opt is None or not self.fuse_update:
+            return None
+        return self.opt.fuse_handle(write_grad=self.keep_grads)
+
     def ready(self, off):
         """True when the completed region [off, hi) should be emitted now.  `chunk_elems` may be a sequence: the k-th slice
         waits for chunk_elems[min(k, last)] elements -- large slices first (their all-reduce has the whole rest of backward
@@ -65,7 +76,7 @@ class BackwardPipeline(object):
             need = self.chunk
         return off < self.hi and ((self.hi - off) >= need or off == 0)
 
-    def run_slice(self, lo, hi):
+    def run_slice(self, lo, hi, fused=()):
         """Runs on the auxiliary stream, after the slice's weight-gradient GEMMs and column reductions.
 
         With a collective the rest of the slice's life -- compression cast, all-reduce, AdamW -- moves to a dedicated
@@ -89,11 +100,11 @@ class BackwardPipeline(object):
                 ev.record(torch.cuda.current_stream())
                 self.comm.wait_event(ev)
                 with torch.cuda.stream(self.comm):
-                    self._update(lo, hi, None)
+                    self._update(lo, hi, None, fused)
                     self.tail_event = torch.cuda.Event()
                     self.tail_event.record(self.comm)
             else:
-                self._update(lo, hi, None)
+                self._update(lo, hi, None, fused)
         elif not sl.is_cuda or not self.use_comm_stream:       # host tensors (gloo tests) / in-line variant
             reduced = None
             if self.compress == "bf16":
@@ -134,7 +145,7 @@ class BackwardPipeline(object):
                 self.tail_event.record(self.comm)
         self.hi = lo
 
-    def _update(self, lo, hi, reduced):
+    def _update(self, lo, hi, reduced, fused=()):
         if reduced is not None and (self.opt is None or self.keep_grads):
             if reduced.is_cuda:
                 from . import ops
@@ -143,7 +154,7 @@ class BackwardPipeline(object):
                 self.engine.flat.G[lo:hi].copy_(reduced)
             reduced = None
         if self.opt is not None:
-            self.opt.apply_range(lo, hi, grad_bf16=reduced)
+            self.opt.apply_range(lo, hi, grad_bf16=reduced, fused=fused)
 
     def end(self):
         """End of backward.  Returns the event the caller's stream must wait on (the communication stream's last work) or None."""

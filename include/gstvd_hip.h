@@ -56,7 +56,10 @@ enum { GSTVD_EPI_BIAS = 1, GSTVD_EPI_ADD = 2, GSTVD_EPI_GELU = 4, GSTVD_EPI_DGEL
        /* grouped weight-gradient launches only (gstvd_gemm_grouped with a k-major A, see gstvd_gemm_group_caps):
         * bias[m] (=|+=) sum_k A[k][m] -- the bias gradient dY^T.1 that autograd computes next to dW = dY^T X, taken from the
         * dY tiles the launch stages anyway (the tiles of column block 0 do it); COLSUM_ACC adds to bias instead of overwriting */
-       GSTVD_EPI_COLSUM = 32, GSTVD_EPI_COLSUM_ACC = 64 };
+       GSTVD_EPI_COLSUM = 32, GSTVD_EPI_COLSUM_ACC = 64,
+       /* gstvd_gemm_grouped_adamw only: C of this problem is a weight's slot of the flat gradient buffer and nothing else adds
+        * to it this step -- the launch applies the AdamW update to the weight in its epilogue (see there) */
+       GSTVD_EPI_ADAMW = 128 };
 
 typedef struct {
   const void* A; const void* B; void* C;
@@ -269,6 +272,36 @@ int gstvd_adamw(float* param, const float* grad, float* m, float* v, void* shado
 int gstvd_adamw_bf16grad(float* param, const void* grad_bf16, int64_t grad_origin, float* m, float* v, void* shadow_bf16,
                          int64_t n, const int64_t* seg_end, const float* hp, int64_t nseg, float beta1, float beta2, float eps,
                          const float* step, float grad_scale, int64_t begin, gstvd_stream_t s);
+
+/* The update of a chosen set of 1024-element blocks of the flat buffers: block_list_dev[b] = index of a block (elements
+ * [1024 k, 1024 k + 1024), absolute), nblocks of them; of those, elements outside [begin, n) and elements of segments with
+ * seg_skip_dev[segment] != 0 are left alone (seg_skip_dev NULL = none).  It is the remainder pass behind
+ * gstvd_gemm_grouped_adamw: biases, LayerNorm and embedding parameters, and any weight whose gradient was accumulated from
+ * several producers. */
+int gstvd_adamw_blocks(float* param, const float* grad, float* m, float* v, void* shadow_bf16, int64_t n,
+                       const int64_t* seg_end, const float* hp, int64_t nseg, float beta1, float beta2, float eps,
+                       const float* step, float grad_scale, int64_t begin, const int32_t* block_list_dev, int64_t nblocks,
+                       const uint8_t* seg_skip_dev, gstvd_stream_t s);
+
+/* Weight gradients and their AdamW update as ONE launch (single-GPU training: no all-reduce stands between a gradient and its
+ * update; train_gen.py:324-329 loss.backward(); optimizer.step(); optimizer.zero_grad()).  A grouped launch like
+ * gstvd_gemm_grouped (bf16 operands, both k-major, fp32 accumulators); for every problem that carries GSTVD_EPI_ADAMW the
+ * tile's epilogue does not store dW but runs the update of gstvd_adamw on its 256 x 256 weights straight from the
+ * accumulators: g = alpha * acc * grad_scale; reads param / m / v, writes param / m / v and the bf16 shadow weights -- 26
+ * bytes per weight instead of 4 (dW out) + 30 (AdamW pass), and the HBM-bound update runs under the MFMA-bound K-loops of the
+ * other workgroups instead of after them.  Such a problem's C must point INTO the flat gradient buffer `grad_base` (its flat
+ * index addresses param / m / v / shadow), with ldc % 4 == 0 and a flat index % 4 == 0; its `addend` field carries the DEVICE
+ * address of the weight's (lr, weight decay) pair -- two consecutive floats, e.g. &hp[2 * segment] of gstvd_adamw's table, read at
+ * run time so that a schedule step needs no new table; it carries no other epilogue flag than COLSUM / COLSUM_ACC.  write_grad
+ * != 0 also stores dW (the `.grad` the caller may want to look at).  Problems without the flag get the plain epilogue.  Same
+ * arithmetic per element as gstvd_gemm_grouped followed by gstvd_adamw: results are bit-identical. */
+typedef struct {
+  const float* grad_base; float* param; float* m; float* v; void* shadow_bf16;
+  const float* step; float beta1, beta2, eps, grad_scale;
+  int32_t write_grad;
+} gstvd_adamw_fuse_t;
+int gstvd_gemm_grouped_adamw(const gstvd_gemm_t* table_dev, const int32_t* tile_off_dev, int64_t nprob, int64_t total_tiles,
+                             const gstvd_adamw_fuse_t* f, gstvd_stream_t s);
 
 /* Measurement support: the (mangled) symbol of the device kernel that gstvd_gemm (splits <= 1) or gstvd_gemm_splitk
  * (splits >= 2) would launch for this descriptor -- the dispatch runs, the launch is replaced by recording its target.

@@ -178,7 +178,9 @@ def test_bench_path_graph_replay_with_pipeline_matches_oracle_in_train_mode(drop
     model.train()
     kw = s.golden_batch(g, DEV)
     opt = FusedAdamW(model, lr=1e-3)
-    BackwardPipeline(model.engine, optimizer=opt, chunk_elems=60000)
+    # keep_grads: this test reads the step's gradients out of the flat buffer afterwards -- in bf16 the single-GPU pipeline lets
+    # the weight-gradient launch update its weights itself and would not store dW otherwise (tests/test_fused_update_gpu.py)
+    BackwardPipeline(model.engine, optimizer=opt, chunk_elems=60000, keep_grads=True)
 
     def device_step():
         loss, _ = model(**kw)
