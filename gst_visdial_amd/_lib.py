@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgstvd_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 F32, BF16 = 0, 1
 EPI_BIAS, EPI_ADD, EPI_GELU, EPI_DGELU, EPI_DROPOUT = 1, 2, 4, 8, 16
@@ -117,6 +117,7 @@ SIGNATURES = {
     "gstvd_adamw_bf16grad": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _f32, _f32, _f32, _vp, _f32, _i64, _vp]),
     "gstvd_adamw_blocks": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _f32, _f32, _f32, _vp, _f32, _i64, _vp, _i64, _vp, _vp]),
     "gstvd_gemm_grouped_adamw": (_i32, [_vp, _vp, _i64, _i64, C.POINTER(AdamFuse), _vp]),
+    "gstvd_gemm_grouped_adamw_kernel_name": (_i32, [C.c_char_p, _i32]),
 }
 
 _STATUS = {-1: "GSTVD_E_DTYPE", -2: "GSTVD_E_SHAPE", -3: "GSTVD_E_ALIGN", -4: "GSTVD_E_NULL", -5: "GSTVD_E_UNSUPPORTED"}

@@ -362,6 +362,9 @@ DEVFN void pp_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char*
 // between (the compiler may not move a load across a store it cannot tell apart from it): 3 D 16-byte loads in flight per lane.
 // Rows / columns outside the matrix: loads are clamped onto a valid element (no branch around a load), stores are masked.
 // Addresses: wave-uniform 64-bit bases + one 32-bit lane offset per row group.
+#ifndef ADAMW_PARK_DEPTH
+#define ADAMW_PARK_DEPTH 5
+#endif
 template <int NI, int ROWS, int D>
 DEVFN void adamw_rows_pass(const gstvd_adamw_fuse_t& af, float alpha, float lr, float wd, float bc, const float* park, int64_t flat0,
                            int rows_left, int cols_left, unsigned ldc, int lane) {
@@ -507,7 +510,7 @@ DEVFN void pc_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char*
               const int cw = pw * 2 + c, cwm = cw / WN, cwn = cw % WN;
               const int64_t mw = m0 + cwm * WTM + h * ROWS, nw = n0 + cwn * WTN;
               const int rows_left = (int)(p.M - mw < ROWS ? p.M - mw : ROWS), cols_left = (int)(p.N - nw < WTN ? p.N - nw : WTN);
-              adamw_rows_pass<NI, ROWS, 5>(af, p.alpha, ad_lr, ad_wd, ad_bc, (const float*)(smem + cw * epi_wave_bytes<NI, HB>()),
+              adamw_rows_pass<NI, ROWS, ADAMW_PARK_DEPTH>(af, p.alpha, ad_lr, ad_wd, ad_bc, (const float*)(smem + cw * epi_wave_bytes<NI, HB>()),
                                            cflat + mw * p.ldc + nw, rows_left, cols_left, (unsigned)p.ldc, lane);
             }
           }
@@ -968,6 +971,16 @@ extern "C" int gstvd_gemm_grouped_kernel_name(int32_t dtype_in, int32_t dtype_ou
   gstvd_plan_capture = nullptr;
   if (rc) return rc;
   const char* name = fn ? hipKernelNameRefByPtr(fn, nullptr) : nullptr;
+  if (!name) return GSTVD_E_UNSUPPORTED;
+  int i = 0;
+  for (; name[i] && i < buf_len - 1; ++i) buf[i] = name[i];
+  buf[i] = 0;
+  return 0;
+}
+
+extern "C" int gstvd_gemm_grouped_adamw_kernel_name(char* buf, int32_t buf_len) {
+  if (!buf || buf_len <= 1) return GSTVD_E_NULL;
+  const char* name = hipKernelNameRefByPtr((const void*)gemm_pc256_grouped_adamw_kernel, nullptr);
   if (!name) return GSTVD_E_UNSUPPORTED;
   int i = 0;
   for (; name[i] && i < buf_len - 1; ++i) buf[i] = name[i];

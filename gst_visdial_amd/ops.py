@@ -267,9 +267,8 @@ class GemmGroup(object):
             items, fl = [], []
             for it in self.items:
                 (a, b, c, M, N, K, lda, ldb, ldc, acc, cs_ptr, cs_acc) = it[:12]
-                hp_addr = 0 if acc else fuse.hp_addr(c, M, N, ldc)
-                if hp_addr:
-                    fl.append(fuse.flat_offset(c))
+                hp_addr, offs = (0, ()) if acc else fuse.cover(c, M, N, ldc)
+                fl.extend(offs)
                 items.append(it[:12] + (hp_addr,))
             if fl:
                 self.items, fused = items, tuple(fl)
@@ -328,7 +327,12 @@ class GemmGroup(object):
             L.check("gstvd_gemm_grouped_adamw", lib.gstvd_gemm_grouped_adamw(tab.data_ptr(), off.data_ptr(), n, tiles, C.byref(fuse.desc()),
                                                                              _stream()))
             if e0 is not None:
-                _prof_end(e0, "gemm:gemm_pc256_grouped_adamw_kernel", flops, nbytes, (n, tiles))
+                name = _KNAME.get("grouped_adamw")
+                if name is None:
+                    buf = C.create_string_buffer(512)
+                    L.check("gstvd_gemm_grouped_adamw_kernel_name", lib.gstvd_gemm_grouped_adamw_kernel_name(buf, 512))
+                    name = _KNAME["grouped_adamw"] = buf.value.decode()
+                _prof_end(e0, "gemm:" + name, flops, nbytes, (n, tiles))
             self.items = []
             return fused
         L.check("gstvd_gemm_grouped", lib.gstvd_gemm_grouped(tab.data_ptr(), off.data_ptr(), n, tiles, self.dtype_in, self.dtype_out,

@@ -64,19 +64,37 @@ class _FuseHandle(object):
         self._desc.grad_scale = self.opt.grad_scale
         return self._desc
 
-    def flat_offset(self, c_ptr):
-        return (c_ptr - self._g0) // 4
-
-    def hp_addr(self, c_ptr, M, N, ldc):
-        """Device address of the (lr, wd) pair of the weight whose gradient slot starts at c_ptr, or 0 when the launch must not
-        update it: not a whole contiguous tensor of the flat buffer, or frozen."""
+    def cover(self, c_ptr, M, N, ldc):
+        """(device address of the (lr, wd) pair, flat offsets of the tensors) of the weight(s) whose gradient slot the contiguous
+        [M, N] block at c_ptr is, or (0, ()) when the launch must not update it.  The block may span several consecutive tensors
+        with the same (lr, wd) -- the fused Q|K|V projections are ONE weight-gradient problem over three tensors -- and may end
+        in alignment padding (the LM head's rows are padded to a multiple of 64: gradient, moments and weights of the padding
+        are zero and stay zero under any lr).  Frozen tensors and blocks that stop inside a tensor are left to the plain path."""
+        opt = self.opt
         off = c_ptr - self._g0
         if off < 0 or off % 16 or ldc != N or N % 4:
-            return 0
-        seg = self.opt.seg_of.get(off // 4)
-        if seg is None or seg[1] != M * N or not self.opt.base[seg[0]][2]:
-            return 0
-        return self.opt.hp.data_ptr() + 8 * seg[0]
+            return 0, ()
+        off //= 4
+        first = opt.seg_of.get(off)
+        if first is None:
+            return 0, ()
+        end, i, offs, hp0 = off + M * N, first[0], [], opt.base[first[0]]
+        if not hp0[2]:
+            return 0, ()
+        pos = off
+        while pos < end and i < len(opt.seg_ends_host):
+            live = opt.base[i][2]
+            if live:
+                if opt.base[i] != hp0 or pos not in opt.seg_of:
+                    return 0, ()
+                offs.append(pos)
+            elif pos in opt.seg_of or opt.seg_ends_host[i] < end:
+                return 0, ()                                # a frozen tensor, or padding in the MIDDLE of the block
+            pos = opt.seg_ends_host[i]
+            i += 1
+        if pos < end or (pos > end and opt.base[i - 1][2]):
+            return 0, ()                                    # stops inside a live tensor
+        return opt.hp.data_ptr() + 8 * first[0], tuple(offs)
 
 
 class FusedAdamW(object):

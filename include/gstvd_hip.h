@@ -302,6 +302,8 @@ typedef struct {
 } gstvd_adamw_fuse_t;
 int gstvd_gemm_grouped_adamw(const gstvd_gemm_t* table_dev, const int32_t* tile_off_dev, int64_t nprob, int64_t total_tiles,
                              const gstvd_adamw_fuse_t* f, gstvd_stream_t s);
+/* measurement support: the (mangled) symbol of the kernel gstvd_gemm_grouped_adamw launches (rocprofv3 traces key on it) */
+int gstvd_gemm_grouped_adamw_kernel_name(char* buf, int32_t buf_len);
 
 /* Measurement support: the (mangled) symbol of the device kernel that gstvd_gemm (splits <= 1) or gstvd_gemm_splitk
  * (splits >= 2) would launch for this descriptor -- the dispatch runs, the launch is replaced by recording its target.

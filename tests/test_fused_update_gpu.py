@@ -62,12 +62,10 @@ class _Fuse(object):
     def desc(self):
         return self.d
 
-    def flat_offset(self, c):
-        return (c - self.g0) // 4
-
-    def hp_addr(self, c, M, N, ldc):
-        seg = self.fl.seg_of.get((c - self.g0) // 4)
-        return 0 if seg is None else self.fl.hp.data_ptr() + 8 * seg
+    def cover(self, c, M, N, ldc):
+        off = (c - self.g0) // 4
+        seg = self.fl.seg_of.get(off)
+        return (0, ()) if seg is None else (self.fl.hp.data_ptr() + 8 * seg, (off,))
 
 
 # (out features M, in features N, batch rows K): full tiles, ragged rows / columns / K, a single-tile problem, a 2-round one

@@ -405,3 +405,38 @@ def test_dropout_counter_hash_has_no_structured_top_byte_collisions():
     a = (_np_drop_hash(seq[: 1 << 16], 0x1234) & 0xffff) >= 6554
     b = (_np_drop_hash(seq[: 1 << 16] + np.uint32(1 << 24), 0x1234) & 0xffff) >= 6554
     assert abs((a == b).mean() - (0.81 + 0.01)) < 0.01
+
+
+def test_fused_update_block_cover_rules():
+    """optim._FuseHandle.cover(): which weight-gradient blocks the grouped launch may update itself (gstvd_gemm_grouped_adamw) --
+    one whole tensor; several consecutive tensors with one (lr, wd) (the fused Q|K|V projections); a tensor followed by alignment
+    padding (the LM head's padded rows); never a frozen tensor, a block that stops inside a tensor, tensors with different
+    hyper-parameters, or a block that does not start a tensor."""
+    from gst_visdial_amd.optim import _FuseHandle
+
+    class T(object):
+        def __init__(self, p):
+            self.p = p
+
+        def data_ptr(self):
+            return self.p
+
+    class O(object):
+        pass
+    opt = O()
+    opt.hp = T(7 << 20)
+    # q, k, v [64 x 32] back to back, a bias, padding, a frozen [64 x 32] tensor, a [60 x 32] head padded to 64 rows
+    opt.seg_ends_host = [2048, 4096, 6144, 6208, 6272, 8320, 10240, 10368]
+    opt.base = [(1e-3, 0.01, 1.0)] * 3 + [(1e-3, 0.0, 1.0), (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), (1e-3, 0.01, 1.0), (0.0, 0.0, 0.0)]
+    opt.seg_of = {0: (0, 2048), 2048: (1, 2048), 4096: (2, 2048), 6144: (3, 64), 6272: (5, 2048), 8320: (6, 1920)}
+    h = _FuseHandle.__new__(_FuseHandle)
+    h.opt, h._g0 = opt, 4096
+    g = lambda off: 4096 + 4 * off
+    hp = lambda seg: (7 << 20) + 8 * seg
+    assert h.cover(g(0), 192, 32, 32) == (hp(0), (0, 2048, 4096))
+    assert h.cover(g(0), 64, 32, 32) == (hp(0), (0,))
+    assert h.cover(g(2048), 128, 32, 32) == (hp(1), (2048, 4096))
+    assert h.cover(g(8320), 64, 32, 32) == (hp(6), (8320,)) and h.cover(g(8320), 60, 32, 32) == (hp(6), (8320,))
+    for args in ((g(0), 160, 32, 32), (g(4096), 66, 32, 32), (g(6272), 64, 32, 32), (g(8320), 70, 32, 32), (g(100), 4, 32, 32),
+                 (g(0), 64, 32, 48), (g(0) + 4, 64, 32, 32), (g(0), 64, 30, 30)):
+        assert h.cover(*args) == (0, ()), args

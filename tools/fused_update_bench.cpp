@@ -103,7 +103,7 @@ int main(int argc, char** argv) {
   auto fused = [&](int c) {
     gstvd_adamw_fuse_t f; memset(&f, 0, sizeof(f));
     f.grad_base = G; f.param = P[c]; f.m = Mo[c]; f.v = V[c]; f.shadow_bf16 = S[c]; f.step = step;
-    f.beta1 = b1; f.beta2 = b2; f.eps = eps; f.grad_scale = gs; f.write_grad = getenv("FUB_DBG") ? atoi(getenv("FUB_DBG")) << 8 : 0;
+    f.beta1 = b1; f.beta2 = b2; f.eps = eps; f.grad_scale = gs; f.write_grad = 0;
     int rc = gstvd_gemm_grouped_adamw(tabf_d, toff_d, np, tiles, &f, s0);
     (void)hipEventRecord(em, s0);
     rc |= gstvd_adamw_blocks(P[c], G, Mo[c], V[c], S[c], n, seg_d, hp_d, nseg, b1, b2, eps, step, gs, 0, blocks_d, (int64_t)blocks.size(), skip_d, s0);
