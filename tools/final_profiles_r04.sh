@@ -36,4 +36,6 @@ GSTVD_FORCE_DIST=1 python3 bench.py --steps 10 --warmup 3 --legs on --no-cpu-bas
 python3 bench.py --steps 10 --warmup 2 --rows-per-gpu 10 --no-cpu-baseline --no-eval-decode --no-fp32 --no-h2d 2>/dev/null | tail -1 > $out/bench_n1_rows10.json
 tail -4 $out/bench_launch_paths.txt | cut -c1-300; cut -c1-200 $out/bench_force_dist_legs.json
 # 9. whole-step A/B records of this round's switches (two interleaved rounds each)
-( bash tools/r04_step_ab.sh GSTVD_GEMM_NT64 0 1 ) > $out/step_ab.txt 2>&1; cat $out/step_ab.txt
+( bash tools/r04_step_ab.sh GSTVD_GEMM_NT64 0 1; bash tools/r04_step_ab.sh GSTVD_FUSE_UPDATE 0 1 ) > $out/step_ab.txt 2>&1; cat $out/step_ab.txt
+# 10. weight gradients + AdamW: two launches against the one launch with the update in its epilogue, stand-alone (C++ over the C ABI)
+( build/fused_update_bench 24 12; build/fused_update_bench 48 24 ) > $out/fused_update_bench.txt 2>&1; tail -4 $out/fused_update_bench.txt

@@ -10,7 +10,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 for f in sorted(glob.glob('gpurun_out/pmc3/*/*/*counter_collection.csv')):
     for r in csv.DictReader(open(f)):
         n = r['Kernel_Name']
-        key = ('gemm_grouped_wgrad_256' if 'grouped' in n else 'gemm_pc256' if 'pc256' in n else 'gemm_dma256' if 'dma256' in n else 'gemm_dma128' if 'Li128ELi128' in n
+        key = ('gemm_grouped_adamw_256' if 'grouped_adamw' in n else 'gemm_grouped_wgrad_256' if 'grouped' in n else 'gemm_pc256' if 'pc256' in n else 'gemm_dma256' if 'dma256' in n else 'gemm_dma128' if 'Li128ELi128' in n
                else 'gemm_dma64' if 'Li64ELi64' in n else 'adamw' if 'adamw' in n else 'ln_bwd' if 'ln_bwd' in n else 'ln_fwd' if 'ln_fwd' in n
                else 'attn' if 'attn' in n else None)
         if key:
