@@ -795,6 +795,12 @@ def main():
             out["kernel_breakdown_ms"] = {k: v["ms"] for k, v in list(breakdown.items())[:12]}
         collective = world > 1 or force_dist
         out["config"]["grad_allreduce_dtype"] = (compress or "fp32") if collective else None
+        # how the optimizer step is applied: inside the weight-gradient launch (single GPU: gstvd_gemm_grouped_adamw + remainder pass,
+        # bit-identical to the two launches) or as a pass of its own behind the slice's all-reduce (N>1)
+        out["config"]["optimizer_update"] = (None if pipe is None else
+                                             "in the weight-gradient launch's epilogue + remainder pass" if pipe.fuse_handle() is not None
+                                             else "AdamW pass per gradient slice")
+        out["config"]["gradient_slices_per_step"] = len(pipe.slices) if pipe is not None else None
         # what the communicator really is (N>1 only runs on the driver's node: this is the evidence that it was RCCL, over how
         # many ranks, with which payload); summing bf16 payloads IN bf16 deviates from the reference's fp32 reduce-add by
         # <= 4e-3 of a tensor's norm at 8 ranks (tests/test_dp_gloo.py::test_eight_rank_graded_slices_bf16_payload_error_bound)

@@ -243,7 +243,7 @@ class FusedAdamW(object):
         key = (lo, hi, fused)
         hit = self._remainders.get(key)
         if hit is None:
-            if torch.cuda.is_current_stream_capturing():
+            if self.seg_end.is_cuda and torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("FusedAdamW: new slice / fusion pattern during a hipGraph capture -- run one eager step first")
             dev = self.seg_end.device
             fused_segs = set(self.seg_of[o][0] for o in fused)

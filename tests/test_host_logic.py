@@ -440,3 +440,27 @@ def test_fused_update_block_cover_rules():
     for args in ((g(0), 160, 32, 32), (g(4096), 66, 32, 32), (g(6272), 64, 32, 32), (g(8320), 70, 32, 32), (g(100), 4, 32, 32),
                  (g(0), 64, 32, 48), (g(0) + 4, 64, 32, 32), (g(0), 64, 30, 30)):
         assert h.cover(*args) == (0, ()), args
+
+
+def test_fused_update_remainder_block_list():
+    """optim.FusedAdamW._remainder(): the 1024-element blocks the remainder pass must visit behind a weight-gradient launch that
+    updated the listed weights itself -- every block that holds a live element of [lo, hi) outside those weights, no block that
+    holds only fused weights / padding / frozen tensors -- and the per-segment skip flags."""
+    import torch
+    from gst_visdial_amd.optim import FusedAdamW
+    opt = FusedAdamW.__new__(FusedAdamW)
+    # layout (elements): embedding [0, 5000) | W1 [5056, 5056 + 8192) | b1 64 | pad | frozen [13376, 14400) | W2 [14400, 14400 + 4096) | b2 [18496, 18560)
+    opt.seg_ends_host = [5000, 5056, 13248, 13312, 13376, 14400, 18496, 18560]
+    live, dead = (1e-3, 0.01, 1.0), (0.0, 0.0, 0.0)
+    opt.base = [live, dead, live, (1e-3, 0.0, 1.0), dead, dead, live, (1e-3, 0.0, 1.0)]
+    opt.seg_of = {0: (0, 5000), 5056: (2, 8192), 13248: (3, 64), 13376: (5, 1024), 14400: (6, 4096), 18496: (7, 64)}
+    opt.seg_end = torch.tensor(opt.seg_ends_host, dtype=torch.int64)
+    opt._remainders = {}
+    blocks, skip = opt._remainder(0, 18560, (5056, 14400))
+    assert skip.tolist() == [0, 0, 1, 0, 0, 0, 1, 0]
+    # embedding: blocks 0..4; b1 [13248, 13312): block 12; b2 [18496, 18560): block 18; the frozen tensor and the padding need none
+    assert blocks.tolist() == [0, 1, 2, 3, 4, 12, 18]
+    blocks, skip = opt._remainder(13248, 18560, (14400,))          # a later slice: W1 is not part of it, the embedding neither
+    assert blocks.tolist() == [12, 18] and skip.tolist() == [0, 0, 0, 0, 0, 0, 1, 0]
+    blocks, _ = opt._remainder(0, 13248, ())                        # nothing fused in this slice: every live block of the range
+    assert blocks.tolist() == list(range(0, (13248 - 1) // 1024 + 1))     # the embedding's blocks 0..4, W1's 4..12

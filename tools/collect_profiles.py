@@ -25,7 +25,7 @@ for a, b in names.items():
         print("profiles/%s_%s" % (tag, b))
 extra = {"r2/repro_raw.log": "repro_gc_capture_raw.log", "r2/repro_guarded.log": "repro_gc_capture_guarded.log",
          "r2/repro_rc.log": "repro_gc_capture_rc.log"}
-for a, b in extra.items():
+for a, b in (extra.items() if "--with-repro" in sys.argv else []):
     p = os.path.join(root, "gpurun_out", a)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, "%s_%s" % (tag, b)))
