@@ -52,17 +52,20 @@ class _FuseHandle(object):
     def __init__(self, opt, write_grad):
         from . import _lib as L
         self.opt, self.write_grad = opt, write_grad
+        self._desc = L.AdamFuse()
+        self._g0 = opt.engine.flat.G.data_ptr()
+
+    def desc(self):
+        """The launch's view of the optimizer, refreshed from the live tensors / constants on every call."""
+        opt, d = self.opt, self._desc
         flat = opt.engine.flat
-        d = L.AdamFuse()
         d.grad_base, d.param, d.m, d.v = flat.G.data_ptr(), flat.P.data_ptr(), opt.m.data_ptr(), opt.v.data_ptr()
         d.shadow_bf16 = flat.S.data_ptr() if flat.S is not None else None
         d.step, d.beta1, d.beta2, d.eps = opt.step_dev.data_ptr(), opt.betas[0], opt.betas[1], opt.eps
-        d.write_grad = int(write_grad)
-        self._desc, self._g0, self._n = d, flat.G.data_ptr(), flat.G.numel()
-
-    def desc(self):
-        self._desc.grad_scale = self.opt.grad_scale
-        return self._desc
+        d.grad_scale, d.write_grad = opt.grad_scale, int(self.write_grad)
+        if d.grad_base != self._g0:
+            raise RuntimeError("FusedAdamW: the flat gradient buffer moved under a live fuse handle")
+        return d
 
     def cover(self, c_ptr, M, N, ldc):
         """(device address of the (lr, wd) pair, flat offsets of the tensors) of the weight(s) whose gradient slot the contiguous
