@@ -305,9 +305,6 @@ int gstvd_gemm_grouped_adamw(const gstvd_gemm_t* table_dev, const int32_t* tile_
 /* measurement support: the (mangled) symbol of the kernel gstvd_gemm_grouped_adamw launches (rocprofv3 traces key on it) */
 int gstvd_gemm_grouped_adamw_kernel_name(char* buf, int32_t buf_len);
 
-/* Measurement support: the (mangled) symbol of the device kernel that gstvd_gemm (splits <= 1) or gstvd_gemm_splitk
- * (splits >= 2) would launch for this descriptor -- the dispatch runs, the launch is replaced by recording its target.
- * bench.py's roofline.kernel comes from here.  Nothing is launched; pointers in the descriptor are not dereferenced. */
 /* Decode step (one token per row, models/visual_dialog_model.py:87-92 with the KV cache of this build): the LayerNorm that
  * closes a BERT sub-layer (transformers 4.16.2 BertSelfOutput / BertOutput, eps 1e-12) folded into the Linear that consumes it:
  * C = epi(LN(A; gamma, beta, eps) . B^T) for M <= 16 rows, K <= 1024, bf16 operands; epilogue flags BIAS / ADD / GELU as in
@@ -316,6 +313,9 @@ int gstvd_gemm_grouped_adamw_kernel_name(char* buf, int32_t buf_len);
 int gstvd_gemv_ln(const gstvd_gemm_t* g, const float* gamma, const float* beta, float eps, void* y_out, int64_t ldy, gstvd_stream_t s);
 /* bit 0: gstvd_gemm_grouped honours GSTVD_EPI_COLSUM (the producer / consumer kernel is the one it launches) */
 int32_t gstvd_gemm_group_caps(void);
+/* Measurement support: the (mangled) symbol of the device kernel that gstvd_gemm (splits <= 1) or gstvd_gemm_splitk
+ * (splits >= 2) would launch for this descriptor -- the dispatch runs, the launch is replaced by recording its target.
+ * bench.py's roofline.kernel comes from here.  Nothing is launched; pointers in the descriptor are not dereferenced. */
 int gstvd_gemm_kernel_name(const gstvd_gemm_t* g, int32_t splits, char* buf, int32_t buf_len);
 int gstvd_gemm_grouped_kernel_name(int32_t dtype_in, int32_t dtype_out, int32_t a_kmajor, int32_t b_kmajor, char* buf, int32_t buf_len);
 
