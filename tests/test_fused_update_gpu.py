@@ -222,3 +222,48 @@ def test_fused_update_under_hipgraph_replay_follows_the_schedule():
         assert (a - b).abs().max().item() <= 2e-5 * max(1.0, a.abs().max().item()), (k, (a - b).abs().max().item())
     moved = (ref["param"] - _run_model(False, 1 << 40, False, 1, False)["param"]).abs().max().item()
     assert moved > 1e-4                                  # the replays really trained
+
+
+@pytest.mark.isolated
+def test_full_size_step_with_the_fused_update_is_bit_identical_to_the_two_launches():
+    """The 388 M-parameter model at the bench shape (16 rows, seq_len 256, bf16, dropout on), one training step from the same
+    state through the single-slice pipeline with and without the fold: 5309 tiles of 197 problems, the fused Q|K|V blocks (three
+    tensors, one problem), the LM head with its rows padded to a multiple of 64, K = 400 / 592 / 4096.  Bit-identical parameters,
+    moments and shadow weights outside the atomically accumulated tables; > 90 % of the parameters took the fused path."""
+    import bench
+    from gst_visdial_amd.optim import FusedAdamW
+    from gst_visdial_amd.pipeline import BackwardPipeline
+
+    def run(fuse):
+        model, params = bench.build_model(torch.device(DEV), "bf16", seed=3)
+        model.train()
+        V = model.decoder.config.vocab_size
+        batch = bench.synthetic_rows(16, 256, 37, 25, 2048, V, 99, DEV)
+        opt = FusedAdamW(model, lr=1e-3, warmup_steps=0, t_total=100)
+        pipe = BackwardPipeline(model.engine, optimizer=opt, chunk_elems=1 << 40)
+        pipe.fuse_update = fuse
+        loss, _ = model(**batch)
+        loss.backward()
+        opt.step()
+        torch.cuda.synchronize()
+        fl = model.engine.flat
+        nfused = 0
+        if fuse:
+            (key, (blocks, skip)), = opt._remainders.items()
+            seg_len = torch.tensor([e - s for s, e in zip([0] + opt.seg_ends_host[:-1], opt.seg_ends_host)])
+            nfused = int(seg_len[skip.cpu().bool()].sum())
+        out = dict(param=fl.P.clone(), m=opt.m.clone(), v=opt.v.clone(), shadow=fl.S.clone(), atomic=_atomic_fed(model), loss=loss.item(),
+                   nfused=nfused, n=fl.n_live)
+        del model, opt, pipe
+        torch.cuda.empty_cache()
+        return out
+
+    ref, got = run(False), run(True)
+    assert ref["loss"] == got["loss"]
+    det = ~ref["atomic"]
+    for k in ("param", "m", "v", "shadow"):
+        a, b = ref[k], got[k]
+        assert torch.equal(a[det], b[det]), (k, (a.float() - b.float())[det].abs().max().item(), int((a != b)[det].sum()))
+        assert (a.float() - b.float()).abs().max().item() < 1e-6, k
+    assert got["nfused"] > 0.9 * got["n"], (got["nfused"], got["n"])
+    assert not torch.equal(ref["param"], ref["shadow"].float())        # (sanity: fp32 masters differ from their bf16 shadows)
