@@ -2,8 +2,9 @@
 // k-major operands, fp32 out, `nb` problems in one launch -- ingest/MFMA-bound) and the fused AdamW over `na` Mi parameters
 // (HBM-bound), each alone and then together on two streams, in both issue orders.  If "together" ~ max(alone) the end of the step
 // (1.45 ms of weight gradients, then 1.72 ms of AdamW, one after the other) can be cut into pieces that run side by side; if it is
-// ~ the sum, it cannot.  GSTVD_ADAMW_BG=W (experiment switch in loss.hip) makes the AdamW launch a resident grid of W workgroups
-// per CU instead of one workgroup per 1024 elements.
+// ~ the sum, it cannot.  (Measured: the sum -- AdamW's one-workgroup-per-block grid takes every wave slot, the GEMM makes no
+// progress until it is through.  A resident-grid AdamW, GSTVD_ADAMW_BG=W workgroups per CU, existed for this probe and is gone
+// again: profiles/r04_overlap_bench.txt, profiles/r04_bg_sweep.txt.  The variable is only echoed now.)
 //   hipcc -O2 --offload-arch=gfx950 tools/overlap_bench.cpp -o build/overlap_bench -Lgst_visdial_amd/lib -lgstvd_hip -Wl,-rpath,$PWD/gst_visdial_amd/lib
 #include <hip/hip_runtime.h>
 #include <stdio.h>
