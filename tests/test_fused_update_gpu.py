@@ -84,8 +84,11 @@ def test_grouped_adamw_is_bit_identical_to_grouped_gemm_then_adamw(write_grad):
     def run(fused):
         P, Mo, V, S, G = fl.state()
         grp = ops.GemmGroup(torch.device(DEV), a_km=True, b_km=True)
-        for (M, N, K), dy, x, off, acc in zip(SHAPES, dys, xs, fl.offs, accumulate):
-            grp.add(dy, x, G[off:off + M * N].view(M, N), M, N, K, acc)
+        biases = [torch.zeros(M, device=DEV) for M, N, K in SHAPES]
+        for i, ((M, N, K), dy, x, off, acc) in enumerate(zip(SHAPES, dys, xs, fl.offs, accumulate)):
+            # every other problem also asks for its bias gradient (column sums of dY) out of the same launch, as the engine does
+            cs = biases[i] if (i % 2 == 0 and grp.colsum_capable(dy)) else None
+            grp.add(dy, x, G[off:off + M * N].view(M, N), M, N, K, acc, colsum_out=cs)
         if fused:
             done = grp.flush(fuse=_Fuse(fl, P, Mo, V, S, G, write_grad))
             assert sorted(done) == sorted(o for o, a in zip(fl.offs, accumulate) if not a)
@@ -103,11 +106,12 @@ def test_grouped_adamw_is_bit_identical_to_grouped_gemm_then_adamw(write_grad):
             assert grp.flush() == ()
             ops.adamw(P, G, Mo, V, S, fl.seg_end, fl.hp, fl.step, grad_scale=0.5, begin=0, end=fl.n)
         torch.cuda.synchronize()
-        return P, Mo, V, S, G
+        return P, Mo, V, S, G, torch.cat(biases)
 
     ref, got = run(False), run(True)
     for name, a, b in zip(("param", "m", "v", "shadow"), ref[:4], got[:4]):
         assert torch.equal(a, b), (name, (a.float() - b.float()).abs().max().item(), int((a != b).sum()))
+    assert torch.equal(ref[5], got[5]) and ref[5].abs().sum().item() > 0      # the bias gradients of the same launch
     assert not torch.equal(ref[0], fl.P0)                        # and something happened
     if write_grad:                                               # the launch also left dW where `.grad` looks for it
         assert torch.equal(ref[4], got[4])
