@@ -347,6 +347,9 @@ def main():
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 parity-mode timing beside the bf16 headline")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive measurement (inputs staged from pinned host memory)")
     ap.add_argument("--no-eval-decode", action="store_true", help="skip the BASELINE configs[3] side measurements (decode / candidate scoring)")
+    ap.add_argument("--shard-update", default="off", choices=["on", "off"],
+                    help="N>1: reduce-scatter the gradient slices, AdamW on the rank's 1/N shard, all-gather the bf16 shadow weights "
+                         "(pipeline.BackwardPipeline(shard_update=True)) instead of all-reduce + the full AdamW on every rank")
     ap.add_argument("--legs", default="auto", choices=["auto", "on", "off"],
                     help="extra N>1 legs beside the headline, each in fresh child processes: 10 rows/rank (BASELINE configs[2]) and the "
                          "reference-faithful fp32 gradient all-reduce (auto: when more than one rank runs)")
@@ -370,9 +373,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
 
+    leg_ports = []
+
     def leg_port(k):
-        """Rendezvous port of the k-th child leg: every rank derives the same number without talking to the others (the parent's
-        own port stays occupied by its launcher's store for the whole run)."""
+        """Rendezvous port of the k-th child leg.  With a process group, rank 0 asked the kernel for free ports right after the
+        group came up and broadcast them (`leg_ports`): the neighbours of MASTER_PORT may be in use, or shared with a second
+        bench on the same host.  Without one (a leg of a 1-rank run) any free port will do."""
+        if k < len(leg_ports):
+            return leg_ports[k]
+        if world == 1:
+            return _free_port()
         return int(os.environ.get("MASTER_PORT", "29511")) + 1 + k
 
     if world != args.gpus:
@@ -409,6 +419,10 @@ def main():
             from gst_visdial_amd.graph import enable_watchdog_introspection
             enable_watchdog_introspection()      # lets the capture wait until c10d's watchdog has retired the warm-up collectives
             dist.init_process_group("nccl", device_id=device)
+        # ports for the child legs, agreed on while the group is young and healthy (nothing is issued on it after a failed capture)
+        ports = [[_free_port() for _ in range(4)] if rank == 0 else None]
+        dist.broadcast_object_list(ports, src=0)
+        leg_ports.extend(int(p) for p in ports[0])
 
     from gst_visdial_amd import ops
     from gst_visdial_amd.optim import FusedAdamW
@@ -450,7 +464,8 @@ def main():
         # decoder's chain (its next kernel waits for the whole update: tools/r04_bg_sweep.sh, profiles/r04_bg_sweep.txt).
         chunk_elems = 1 << 40
     pipe = None if args.no_pipeline else BackwardPipeline(model.engine, optimizer=opt, chunk_elems=chunk_elems,
-                                                          compress=compress, force_collective=force_dist)
+                                                          compress=compress, force_collective=force_dist,
+                                                          shard_update=(args.shard_update == "on" and (world > 1 or force_dist)))
 
     def device_step():
         """Everything of a train step that is device work -- the part that is captured into the hipGraph."""
@@ -799,7 +814,8 @@ def main():
         # bit-identical to the two launches) or as a pass of its own behind the slice's all-reduce (N>1)
         out["config"]["optimizer_update"] = (None if pipe is None else
                                              "in the weight-gradient launch's epilogue + remainder pass" if pipe.fuse_handle() is not None
-                                             else "AdamW pass per gradient slice")
+                                             else "sharded: reduce-scatter -> AdamW on the rank's 1/N shard -> all-gather of the bf16 shadow weights"
+                                             if (pipe.shard_update and pipe.collective) else "AdamW pass per gradient slice (full, on every rank)")
         out["config"]["gradient_slices_per_step"] = len(pipe.slices) if pipe is not None else None
         # what the communicator really is (N>1 only runs on the driver's node: this is the evidence that it was RCCL, over how
         # many ranks, with which payload); summing bf16 payloads IN bf16 deviates from the reference's fp32 reduce-add by
@@ -828,6 +844,9 @@ def main():
             legs.append(("rows10", ["--rows-per-gpu", "10"]))
         if compress is not None:
             legs.append(("fp32_allreduce", ["--grad-compress", "none"]))
+        if args.shard_update != "on":
+            # the same step with the optimizer sharded over the ranks (1/N of the AdamW pass per rank, same bytes on the links)
+            legs.append(("sharded_update", ["--shard-update", "on"]))
         for k, (name, extra) in enumerate(legs):
             res = run_leg(name, extra, argv, rank, world, local, leg_port(1 + k))
             if rank == 0:
@@ -835,7 +854,7 @@ def main():
                     c = res.get("config", {})
                     res = {"value": res.get("value"), "unit": res.get("unit"), "ms_per_step": res.get("ms_per_step"), "n_gpus": res.get("n_gpus"),
                            "rows_per_gpu": c.get("rows_per_gpu"), "global_batch": c.get("global_batch"), "hip_graph": c.get("hip_graph"),
-                           "grad_allreduce_dtype": c.get("grad_allreduce_dtype"),
+                           "grad_allreduce_dtype": c.get("grad_allreduce_dtype"), "optimizer_update": c.get("optimizer_update"),
                            "ranks_seen_by_allreduce": (c.get("rccl") or {}).get("ranks_seen_by_allreduce"), "workload": c.get("workload")}
                 out["config"].setdefault("legs", {})[name] = res
                 if name == "rows10" and world == 8:

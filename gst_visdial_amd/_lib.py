@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgstvd_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 F32, BF16 = 0, 1
 EPI_BIAS, EPI_ADD, EPI_GELU, EPI_DGELU, EPI_DROPOUT = 1, 2, 4, 8, 16
@@ -88,7 +88,7 @@ SIGNATURES = {
     "gstvd_gemv_ln": (_i32, [C.POINTER(GemmDesc), _vp, _vp, _f32, _vp, _i64, _vp]),
     "gstvd_gemm_kernel_name": (_i32, [C.POINTER(GemmDesc), _i32, C.c_char_p, _i32]),
     "gstvd_gemm_grouped_kernel_name": (_i32, [_i32, _i32, _i32, _i32, C.c_char_p, _i32]),
-    "gstvd_gemm_grouped": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "gstvd_gemm_grouped": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
     "gstvd_ln_fwd": (_i32, [C.POINTER(LnDesc), _vp]),
     "gstvd_ln_bwd_blocks": (_i64, [_i64]),
     "gstvd_ln_bwd_blocks_for": (_i64, [_i64, _i64, _i32]),
@@ -116,7 +116,7 @@ SIGNATURES = {
     "gstvd_adamw": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _f32, _f32, _f32, _vp, _f32, _i64, _vp]),
     "gstvd_adamw_bf16grad": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _f32, _f32, _f32, _vp, _f32, _i64, _vp]),
     "gstvd_adamw_blocks": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _f32, _f32, _f32, _vp, _f32, _i64, _vp, _i64, _vp, _vp]),
-    "gstvd_gemm_grouped_adamw": (_i32, [_vp, _vp, _i64, _i64, C.POINTER(AdamFuse), _vp]),
+    "gstvd_gemm_grouped_adamw": (_i32, [_vp, _vp, _i64, _i64, C.POINTER(AdamFuse), _vp, _i64, _vp]),
     "gstvd_gemm_grouped_adamw_kernel_name": (_i32, [C.c_char_p, _i32]),
 }
 

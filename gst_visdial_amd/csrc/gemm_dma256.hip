@@ -503,7 +503,8 @@ DEVFN void pc_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char*
         const int64_t cflat = (const float*)p.C - af.grad_base;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          __builtin_amdgcn_s_barrier();                    // the consumers have parked half h
+          __builtin_amdgcn_s_barrier();                    // the consumers have parked half h (they waited lgkmcnt(0) before arriving)
+          asm volatile("" ::: "memory");                   // no park read may be scheduled above the barrier
           if (ad_lr != 0.f) {
 #pragma unroll
             for (int c = 0; c < 2; ++c) {                  // this producer wave serves consumer waves 2 pw and 2 pw + 1
@@ -514,7 +515,10 @@ DEVFN void pc_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char*
                                            cflat + mw * p.ldc + nw, rows_left, cols_left, (unsigned)p.ldc, lane);
             }
           }
-          if (h == 0) __builtin_amdgcn_s_barrier();        // the parks may be overwritten
+          if (h == 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every park read of this wave has returned
+            __builtin_amdgcn_s_barrier();                  // the parks may be overwritten
+          }
         }
       }
     }
@@ -564,12 +568,19 @@ DEVFN void pc_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char*
       float* park = (float*)(smem + wave * epi_wave_bytes<NI, HB>());
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        if (h) __builtin_amdgcn_s_barrier();              // the producers are done with the first half
+        if (h) {
+          __builtin_amdgcn_s_barrier();                    // the producers are done with the first half
+          asm volatile("" ::: "memory");
+        }
 #pragma unroll
         for (int i = 0; i < HB; ++i)
 #pragma unroll
           for (int j = 0; j < NI; ++j) *(f32x4*)(park + (i * 16 + li) * S + j * 16 + 4 * g) = acc[h * HB + i][j];
-        __builtin_amdgcn_s_barrier();                      // parked (a barrier waits for the wave's LDS writes)
+        // The park crosses waves (the producers read it), and s_barrier on gfx950 waits for no counter: the LDS writes must
+        // have retired before this wave arrives, and the compiler may not move them across the barrier either.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // parked
+        asm volatile("" ::: "memory");
       }
       return;
     }
@@ -755,13 +766,26 @@ __global__ __launch_bounds__(768) void gemm_pc256_nt64_kernel(GemmP p, int ntn, 
   pc_tile256_nt64<OT, NIU>(p, blockIdx.y, xcd_remap256(blockIdx.x, nwg), ntn, nwg, smem);
 }
 
+// Which tile of the table a workgroup of a grouped launch runs.
+//   bmap != nullptr (the host's order, ops.GemmGroup: gstvd_gemm_grouped*'s `block_map_dev`): block b runs tile bmap[b], or
+//     nothing when that is negative (padding of the shorter XCD queues).  Blocks are dealt to the XCDs round-robin (observed, speed
+//     only), so entries b = x, x + 8, x + 16, ... are XCD x's queue: the host puts whole problems -- tiles that share operand
+//     panels and run for the same time -- back to back into ONE queue, so that the ~32 tiles an XCD runs at a time stream the
+//     same few panels through its L2 in step.
+//   bmap == nullptr: XCD x walks chunks x, x+8, x+16, ... of 2^chs consecutive tiles (rounds 1-4).
+DEVFN int grouped_tile_id(const int* bmap, int total, int chs) {
+  const int bid = blockIdx.x;
+  if (bmap) return bmap[bid];
+  const int full = total - total % (8 << chs);
+  return bid < full ? (((bid >> 3) >> chs) * 8 + (bid & 7)) * (1 << chs) + ((bid >> 3) & ((1 << chs) - 1)) : bid;
+}
+
 template <typename OT, bool AKM, bool BKM, int PF, int ST = 0>
-__global__ __launch_bounds__(512) void gemm_dma256_grouped_kernel(const gstvd_gemm_t* tab, const int* tile_off, int nprob, int total, int chs) {
+__global__ __launch_bounds__(512) void gemm_dma256_grouped_kernel(const gstvd_gemm_t* tab, const int* tile_off, int nprob, int total, int chs,
+                                                                  const int* bmap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // XCD x (blocks b with b % 8 == x) walks chunks x, x+8, x+16, ... of 2^chs consecutive tiles: neighbours in the table share
-  // operands (one problem ~ one chunk), and long-K and short-K problems are spread over all eight XCDs
-  const int full = total - total % (8 << chs), bid = blockIdx.x;
-  const int gid = bid < full ? (((bid >> 3) >> chs) * 8 + (bid & 7)) * (1 << chs) + ((bid >> 3) & ((1 << chs) - 1)) : bid;
+  const int gid = grouped_tile_id(bmap, total, chs);
+  if (gid < 0) return;
   int lo = 0, hi = nprob - 1;
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tile_off[mid] <= gid) lo = mid; else hi = mid - 1; }
   const gstvd_gemm_t& g = tab[lo];
@@ -888,10 +912,11 @@ int gemm_dma256_dispatch(const GemmP& p, int64_t batch, int akm, int bkm, int ou
 }
 
 template <typename OT, bool AKM, bool BKM>
-__global__ __launch_bounds__(768) void gemm_pc256_grouped_kernel(const gstvd_gemm_t* tab, const int* tile_off, int nprob, int total, int chs) {
+__global__ __launch_bounds__(768) void gemm_pc256_grouped_kernel(const gstvd_gemm_t* tab, const int* tile_off, int nprob, int total, int chs,
+                                                                 const int* bmap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int full = total - total % (8 << chs), bid = blockIdx.x;
-  const int gid = bid < full ? (((bid >> 3) >> chs) * 8 + (bid & 7)) * (1 << chs) + ((bid >> 3) & ((1 << chs) - 1)) : bid;
+  const int gid = grouped_tile_id(bmap, total, chs);
+  if (gid < 0) return;
   int lo = 0, hi = nprob - 1;
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tile_off[mid] <= gid) lo = mid; else hi = mid - 1; }
   const gstvd_gemm_t& g = tab[lo];
@@ -907,10 +932,10 @@ __global__ __launch_bounds__(768) void gemm_pc256_grouped_kernel(const gstvd_gem
 }
 
 __global__ __launch_bounds__(768) void gemm_pc256_grouped_adamw_kernel(const gstvd_gemm_t* tab, const int* tile_off, int nprob, int total, int chs,
-                                                                       gstvd_adamw_fuse_t af) {
+                                                                       const int* bmap, gstvd_adamw_fuse_t af) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int full = total - total % (8 << chs), bid = blockIdx.x;
-  const int gid = bid < full ? (((bid >> 3) >> chs) * 8 + (bid & 7)) * (1 << chs) + ((bid >> 3) & ((1 << chs) - 1)) : bid;
+  const int gid = grouped_tile_id(bmap, total, chs);
+  if (gid < 0) return;
   int lo = 0, hi = nprob - 1;
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tile_off[mid] <= gid) lo = mid; else hi = mid - 1; }
   const gstvd_gemm_t& g = tab[lo];
@@ -926,7 +951,7 @@ __global__ __launch_bounds__(768) void gemm_pc256_grouped_adamw_kernel(const gst
 }
 
 template <typename OT, bool AKM, bool BKM>
-static int grouped256(const gstvd_gemm_t* tab, const int* off, int nprob, int total, hipStream_t s) {
+static int grouped256(const gstvd_gemm_t* tab, const int* off, int nprob, int total, const int* bmap, int nblocks, hipStream_t s) {
   auto k0 = gemm_dma256_grouped_kernel<OT, AKM, BKM, 0>;
   auto k4 = gemm_dma256_grouped_kernel<OT, AKM, BKM, 0, 4>;
   static int attr_rc = ensure_lds(k0, LDS256) | ensure_lds(k4, LDS256);
@@ -941,11 +966,11 @@ static int grouped256(const gstvd_gemm_t* tab, const int* off, int nprob, int to
     auto kp = gemm_pc256_grouped_kernel<OT, AKM, BKM>;
     static int pc_rc = ensure_lds(kp, LDS256);
     if (pc_rc) return pc_rc;
-    GSTVD_LAUNCH(kp, dim3((unsigned)total), dim3(768), LDS256, s, tab, off, nprob, total, chs);
+    GSTVD_LAUNCH(kp, dim3((unsigned)(bmap ? nblocks : total)), dim3(768), LDS256, s, tab, off, nprob, total, chs, bmap);
     GSTVD_LAUNCH_CHECK();
     return 0;
   }
-  GSTVD_LAUNCH(st == 4 ? k4 : k0, dim3((unsigned)total), dim3(512), LDS256, s, tab, off, nprob, total, chs);
+  GSTVD_LAUNCH(st == 4 ? k4 : k0, dim3((unsigned)(bmap ? nblocks : total)), dim3(512), LDS256, s, tab, off, nprob, total, chs, bmap);
   GSTVD_LAUNCH_CHECK();
   return 0;
 }
@@ -967,7 +992,7 @@ extern "C" int gstvd_gemm_grouped_kernel_name(int32_t dtype_in, int32_t dtype_ou
   static gstvd_gemm_t dummy_tab;
   static int32_t dummy_off;
   gstvd_plan_capture = &fn;
-  const int rc = gstvd_gemm_grouped(&dummy_tab, &dummy_off, 1, 1, dtype_in, dtype_out, a_kmajor, b_kmajor, nullptr);
+  const int rc = gstvd_gemm_grouped(&dummy_tab, &dummy_off, 1, 1, dtype_in, dtype_out, a_kmajor, b_kmajor, nullptr, 0, nullptr);
   gstvd_plan_capture = nullptr;
   if (rc) return rc;
   const char* name = fn ? hipKernelNameRefByPtr(fn, nullptr) : nullptr;
@@ -997,36 +1022,41 @@ extern "C" int gstvd_debug_gemm_clock(uint64_t* out_host, int32_t n_words) {
 #endif
 
 extern "C" int gstvd_gemm_grouped_adamw(const gstvd_gemm_t* table_dev, const int32_t* tile_off_dev, int64_t nprob, int64_t total_tiles,
-                                        const gstvd_adamw_fuse_t* f, gstvd_stream_t stream) {
+                                        const gstvd_adamw_fuse_t* f, const int32_t* block_map_dev, int64_t nblocks, gstvd_stream_t stream) {
   if (!table_dev || !tile_off_dev || !f) return GSTVD_E_NULL;
   if (!f->grad_base || !f->param || !f->m || !f->v || !f->step) return GSTVD_E_NULL;
   if (nprob <= 0 || total_tiles <= 0) return GSTVD_E_SHAPE;
+  if (block_map_dev && nblocks < total_tiles) return GSTVD_E_SHAPE;     // a map that cannot name every tile
   if (((uintptr_t)f->grad_base | (uintptr_t)f->param | (uintptr_t)f->m | (uintptr_t)f->v | (uintptr_t)f->shadow_bf16) & 15) return GSTVD_E_ALIGN;
   if (!(gstvd_gemm_group_caps() & 1)) return GSTVD_E_UNSUPPORTED;     // the producer / consumer tile is switched off (tuning runs)
   auto kp = gemm_pc256_grouped_adamw_kernel;
   static int rc = ensure_lds(kp, LDS256);
   if (rc) return rc;
   static const int chs = [] { const char* e = getenv("GSTVD_GROUP_CHUNK_LOG2"); const int v = e ? atoi(e) : 3; return v < 0 ? 0 : (v > 10 ? 10 : v); }();
-  GSTVD_LAUNCH(kp, dim3((unsigned)total_tiles), dim3(768), LDS256, (hipStream_t)stream, table_dev, tile_off_dev, (int)nprob, (int)total_tiles, chs, *f);
+  GSTVD_LAUNCH(kp, dim3((unsigned)(block_map_dev ? nblocks : total_tiles)), dim3(768), LDS256, (hipStream_t)stream, table_dev, tile_off_dev,
+               (int)nprob, (int)total_tiles, chs, block_map_dev, *f);
   GSTVD_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int gstvd_gemm_grouped(const gstvd_gemm_t* table_dev, const int32_t* tile_off_dev, int64_t nprob, int64_t total_tiles,
-                                  int32_t dtype_in, int32_t dtype_out, int32_t a_kmajor, int32_t b_kmajor, gstvd_stream_t stream) {
+                                  int32_t dtype_in, int32_t dtype_out, int32_t a_kmajor, int32_t b_kmajor,
+                                  const int32_t* block_map_dev, int64_t nblocks, gstvd_stream_t stream) {
   if (!table_dev || !tile_off_dev) return GSTVD_E_NULL;
   if (nprob <= 0 || total_tiles <= 0) return GSTVD_E_SHAPE;
+  if (block_map_dev && nblocks < total_tiles) return GSTVD_E_SHAPE;     // a map that cannot name every tile
   if (dtype_in != GSTVD_BF16) return GSTVD_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  const int n = (int)nprob, t = (int)total_tiles;
+  const int n = (int)nprob, t = (int)total_tiles, nb = (int)nblocks;
+  const int* bm = block_map_dev;
   if (dtype_out == GSTVD_F32) {
-    if (a_kmajor && b_kmajor) return grouped256<float, true, true>(table_dev, tile_off_dev, n, t, s);
-    if (!a_kmajor && b_kmajor) return grouped256<float, false, true>(table_dev, tile_off_dev, n, t, s);
-    if (!a_kmajor && !b_kmajor) return grouped256<float, false, false>(table_dev, tile_off_dev, n, t, s);
+    if (a_kmajor && b_kmajor) return grouped256<float, true, true>(table_dev, tile_off_dev, n, t, bm, nb, s);
+    if (!a_kmajor && b_kmajor) return grouped256<float, false, true>(table_dev, tile_off_dev, n, t, bm, nb, s);
+    if (!a_kmajor && !b_kmajor) return grouped256<float, false, false>(table_dev, tile_off_dev, n, t, bm, nb, s);
   } else if (dtype_out == GSTVD_BF16) {
-    if (a_kmajor && b_kmajor) return grouped256<bf16, true, true>(table_dev, tile_off_dev, n, t, s);
-    if (!a_kmajor && b_kmajor) return grouped256<bf16, false, true>(table_dev, tile_off_dev, n, t, s);
-    if (!a_kmajor && !b_kmajor) return grouped256<bf16, false, false>(table_dev, tile_off_dev, n, t, s);
+    if (a_kmajor && b_kmajor) return grouped256<bf16, true, true>(table_dev, tile_off_dev, n, t, bm, nb, s);
+    if (!a_kmajor && b_kmajor) return grouped256<bf16, false, true>(table_dev, tile_off_dev, n, t, bm, nb, s);
+    if (!a_kmajor && !b_kmajor) return grouped256<bf16, false, false>(table_dev, tile_off_dev, n, t, bm, nb, s);
   }
   return GSTVD_E_UNSUPPORTED;
 }

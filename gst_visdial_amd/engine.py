@@ -267,6 +267,31 @@ class FlatParams(object):
             ops.cast(self.P, self.S)
             self.shadow_version = v
 
+    def fp32_read_ranges(self):
+        """Sorted, disjoint flat ranges [x, y) whose fp32 values the forward reads directly (Engine.Pv: biases, LayerNorm gain /
+        bias, the embedding tables, the image-location projection) -- everything in [0, n_live) that is not EXCLUSIVELY a GEMM
+        weight (Engine.W: read from the bf16 shadow buffer in bf16 mode).  pipeline.BackwardPipeline(shard_update=True) gathers
+        these in fp32; the GEMM weights only travel as bf16 shadows."""
+        def numel(shape):
+            n = 1
+            for d in shape:
+                n *= d
+            return n
+        non_gemm = ("ln.w", "ln1.w", "ln2.w", "ln3.w", "vln.w", "tln.w", "vemb.loc.w")
+        by_start = {}
+        for name, (off, shape) in self.slots.items():
+            gemm = name.endswith(".w") and not name.endswith(non_gemm)
+            by_start.setdefault((off, numel(shape)), []).append(gemm)
+        shadow_only = sorted(k for k, flags in by_start.items() if all(flags))      # (the tied LM head aliases an embedding table: not all)
+        out, pos = [], 0
+        for off, n in shadow_only:
+            if off > pos:
+                out.append((pos, off))
+            pos = max(pos, off + n)
+        if pos < self.n_live:
+            out.append((pos, self.n_live))
+        return out
+
     def view(self, buf, name):
         off, shape = self.slots[name]
         n = 1
@@ -357,7 +382,14 @@ class Engine(object):
         if self.flat is None or self.flat.topo != topo:
             self.flat = FlatParams(self.model, self.precision)
             self.flat.topo = topo
-        if not self.flat.is_materialized() or self.flat.device != device:
+        if self.flat.is_materialized() and self.flat.device != device:
+            # the parameters live (as views of the flat buffer) on one device and the inputs arrive on another: a replica of
+            # nn.DataParallel(model, [0, 1, ...]) (train_gen.py:295, README.md:89) -- replicas would share this one engine
+            raise GstvdError(
+                "inputs on %s but the model's parameters are on %s: gst_visdial_amd runs one process per GPU.  "
+                "nn.DataParallel(model, [0]) is fine; for N GPUs launch N ranks (torchrun --nproc-per-node N) and attach "
+                "pipeline.BackwardPipeline for the gradient all-reduce (INTEGRATION.md, 'Multi-GPU')" % (device, self.flat.device))
+        if not self.flat.is_materialized():
             self.flat.materialize(device)
             self._bind_views()
             self._decode_sessions.clear()         # captured graphs address the old buffers
@@ -652,6 +684,11 @@ class Engine(object):
             gv, acc = self.grad_slot(prefix + n)
             if not acc:
                 gv.zero_()
+            elif self.wgrads.pending_into(gv):
+                # the LM head tied to this table (FlatParams aliases lm.w onto it when train_gen.py:293 was not applied) has its
+                # weight-gradient GEMM queued: run the queue now, in order, WITHOUT the fused update -- the scatter-add below is a
+                # second contribution to the same slot, and a GEMM launched later would overwrite it
+                self.wgrads.flush()
             tabs.append(gv)
         nblk = ops.ln_bwd_blocks(M)
         partial = self.arena.alloc(nblk * 4 * H, torch.float32)
@@ -993,8 +1030,16 @@ class Engine(object):
             self.aux_busy = False
         self.wgrads.flush()
         self.colsums.flush()
-        for p, gv in zip(flat.live, flat.grad_views):
-            p.grad = gv
+        stale = self.pipe.stale_grad_offsets() if self.pipe is not None else ()
+        if stale:
+            # the weight-gradient launch updated these weights in its epilogue and never stored dW: `.grad` stays None (a view
+            # of the flat buffer would show an older step's bytes to gradient clipping / logging, and the next backward would
+            # accumulate onto them); BackwardPipeline(keep_grads=True) materialises them
+            for (p, off), gv in zip(flat.items, flat.grad_views):
+                p.grad = None if off in stale else gv
+        else:
+            for p, gv in zip(flat.live, flat.grad_views):
+                p.grad = gv
         fa = st["I"].get("feats_act")
         if st["I"]["feats_grad"] and fa is not None and fa.g is not None:
             return fa.g.float()

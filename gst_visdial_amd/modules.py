@@ -338,6 +338,23 @@ class EncoderDecoderModel(nn.Module):
             object.__setattr__(self.decoder, "_standalone_engine", self._engine)
         return self._engine
 
+    def state_dict(self, *args, **kwargs):
+        eng = self._engine
+        if eng is not None and getattr(eng, "pipe", None) is not None and hasattr(eng.pipe, "check_master_current"):
+            eng.pipe.check_master_current("model.state_dict()")
+        return super().state_dict(*args, **kwargs)
+
+    def _replicate_for_data_parallel(self):
+        """nn.DataParallel(model, [0, 1, 2, 3]) (train_gen.py:295, README.md:89) replicates the module tree per device and runs the
+        replicas in threads; the replicas would all drive ONE engine (one flat parameter buffer, one arena, one tape).  Refuse
+        loudly instead: this framework scales as one process per GPU.  (`nn.DataParallel(model, [0])` never replicates.)"""
+        from ._lib import GstvdError
+        raise GstvdError(
+            "gst_visdial_amd.EncoderDecoderModel cannot be replicated by nn.DataParallel over several device ids: it runs one "
+            "process per GPU.  Keep nn.DataParallel(model, [local_gpu]) for the reference's `.module` access and launch N ranks "
+            "(torchrun --nproc-per-node N train script) with gst_visdial_amd.pipeline.BackwardPipeline doing the gradient "
+            "all-reduce over RCCL (INTEGRATION.md, 'Multi-GPU').")
+
     def score_candidates(self, enc_image_features, enc_image_spatials, enc_image_mask, enc_input_ids, enc_segments,
                          enc_attention_mask, dec_input_ids, dec_attention_mask, num_options):
         """Generative ranking scores of evaluate_gen.py:45-106 with one encoder pass per dialog round (see

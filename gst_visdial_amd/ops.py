@@ -222,6 +222,76 @@ def _splitk_scratch(device):
     return ws
 
 
+GROUP_ORDER = int(os.environ.get("GSTVD_GROUP_ORDER", "2"))       # 0: the library's own chunked order (rounds 1-4); 1 / 2: xcd_block_map
+N_XCD = 8
+GROUP_ORDER_MIN_TILES = 4 * N_XCD * 32      # a few rounds of the chip at least: below that the order is moot (tests lower it)
+
+
+def xcd_block_map(shapes, tile, fused_epilogue, mode=2, unit_tiles=40):
+    """Placement of a grouped launch's tiles (gstvd_gemm_grouped*'s block_map_dev): -> list of tile ids, one per workgroup, -1 =
+    idle; entries b, b + 8, b + 16, ... are the queue of ONE XCD (workgroups are dealt to the eight XCDs round-robin).
+
+    Why: a 256 x 256 weight-gradient tile streams two [K, 256] operand panels (K = the batch rows: 2 MB each at K = 4096) and the
+    36 tiles of a [3072, 768] problem share 15 panels between them.  They only meet in an XCD's 4 MB L2 when they run on that XCD
+    AT THE SAME TIME: the ~32 tiles an XCD has in flight must belong to the same problem(s) and walk K in step.  Rounds 1-4 dealt
+    chunks of 8 tiles round-robin, so an XCD's 32 tiles were four chunks from four places of a table that mixes K = 400 / 592 /
+    4096 problems: equal-K tiles drifted apart within a round or two and the launch fetched its operands 3.5x (r04_pmc_traffic).
+    Here: (1) a problem (or, for the few large ones, a contiguous range of <= `unit_tiles` of its tiles) is a UNIT that goes to
+    one XCD whole; (2) units are sorted into classes of equal K -- equal running time -- long K first, and dealt to the XCD
+    with the least work so far (LPT), so every queue is long-K units back to back, then the short ones: tiles that start
+    together finish together and the next 32 start together again; (3) mode 2: XCD x first runs x/8 of a long tile's time
+    worth of SHORT units -- the eight XCDs then sit in different phases of the K-loop / epilogue cycle, and one XCD's
+    HBM-bound AdamW epilogues (fused launch) run under the other XCDs' MFMA-bound K-loops instead of all at once.
+    `shapes`: [(M, N, K)] per problem in table order; tile ids follow tile_off (problem after problem)."""
+    T = tile
+    units = []                                   # (K, first tile id, number of tiles)
+    gid = 0
+    for (M, N, K) in shapes:
+        nt = ((M + T - 1) // T) * ((N + T - 1) // T)
+        parts = max(1, (nt + unit_tiles - 1) // unit_tiles)
+        base, extra, t0 = nt // parts, nt % parts, gid
+        for i in range(parts):
+            n = base + (1 if i < extra else 0)
+            units.append((K, t0, n))
+            t0 += n
+        gid += nt
+    epi = 30.0 if fused_epilogue else 9.0        # us per tile outside the K loop (fused: 1.7 MB of optimizer state per tile)
+
+    def cost(K, n):
+        return n * (epi + 5.0 + 0.76 * ((K + 31) // 32))
+
+    kmax = max(u[0] for u in units)
+    long_u = sorted([u for u in units if 2 * u[0] > kmax], key=lambda u: (-u[0], -u[2], u[1]))
+    short_u = sorted([u for u in units if 2 * u[0] <= kmax], key=lambda u: (-u[0], -u[2], u[1]))
+    load = [0.0] * N_XCD
+    ql, qs = [[] for _ in range(N_XCD)], [[] for _ in range(N_XCD)]
+    for group, dst in ((long_u, ql), (short_u, qs)):
+        for u in group:
+            x = min(range(N_XCD), key=lambda i: (load[i], i))
+            dst[x].append(u)
+            load[x] += cost(u[0], u[2])
+    queues = []
+    for x in range(N_XCD):
+        lead = []
+        if mode == 2 and ql[x] and qs[x]:
+            t_long = cost(ql[x][0][0], 1)
+            want = t_long * x / N_XCD            # us of lead-in on this XCD
+            got = 0.0
+            while qs[x] and got + 1e-9 < want:
+                u = qs[x].pop()                  # from the end: the shortest units
+                lead.append(u)
+                got += cost(u[0], u[2]) / 32.0   # ~32 tiles of an XCD run at a time
+        q = []
+        for (_, t0, n) in lead + ql[x] + qs[x]:
+            q.extend(range(t0, t0 + n))
+        queues.append(q)
+    depth = max(len(q) for q in queues)
+    out = [-1] * (depth * N_XCD)
+    for x, q in enumerate(queues):
+        out[x:x + len(q) * N_XCD:N_XCD] = q
+    return out
+
+
 class GemmGroup(object):
     """Deferred GEMMs that share dtypes / operand layouts, executed as ONE grouped launch (gstvd_gemm_grouped).
     The engine queues every weight-gradient GEMM of a backward pass here.  Device tables are cached by content
@@ -254,6 +324,25 @@ class GemmGroup(object):
     def reset(self):
         self.items, self.keep = [], []
 
+    def pending_into(self, C_out):
+        """True when a queued problem writes the block that starts at C_out's address.  A NON-GEMM writer into the same gradient
+        slot (the embedding scatter-add when the LM head is tied to the decoder's own word embedding) asks this before it
+        accumulates: the queued GEMM would otherwise run later and overwrite what was added."""
+        ptr = _p(C_out)
+        return any(it[2] == ptr for it in self.items)
+
+    @staticmethod
+    def _overlapping(items):
+        """Indices of queued problems whose C block shares bytes with another queued problem's (sorted sweep over [lo, hi))."""
+        spans = sorted((it[2], it[2] + 4 * ((it[3] - 1) * it[8] + it[4]), i) for i, it in enumerate(items))
+        bad, reach, owner = set(), -1, -1
+        for lo, hi, i in spans:
+            if lo < reach:
+                bad.add(i); bad.add(owner)
+            if hi > reach:
+                reach, owner = hi, i
+        return bad
+
     def flush(self, fuse=None):
         """Launch the queued problems.  `fuse` (optim.FusedAdamW.fuse_handle(), single-GPU training only): every queued weight
         gradient that is the ONLY contribution to its weight this step gets GSTVD_EPI_ADAMW -- the launch updates the weight in
@@ -265,9 +354,12 @@ class GemmGroup(object):
         fused = ()
         if fuse is not None and self.dtype_in == BF16 and self.dtype_out == F32 and self.a_km and self.b_km:
             items, fl = [], []
-            for it in self.items:
+            # a weight is updated in the launch only when this problem is the ONLY contribution to it this step: not when it
+            # accumulates, and not when another queued problem (accumulating or not) writes into the same block
+            shared = self._overlapping(self.items)
+            for i, it in enumerate(self.items):
                 (a, b, c, M, N, K, lda, ldb, ldc, acc, cs_ptr, cs_acc) = it[:12]
-                hp_addr, offs = (0, ()) if acc else fuse.cover(c, M, N, ldc)
+                hp_addr, offs = (0, ()) if (acc or i in shared) else fuse.cover(c, M, N, ldc)
                 fl.extend(offs)
                 items.append(it[:12] + (hp_addr,))
             if fl:
@@ -316,16 +408,21 @@ class GemmGroup(object):
                     nbytes += esz_in * (M * K + K * N) + esz_out * M * N * (2 if acc else 1)
             tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
             off = torch.tensor(offs, dtype=torch.int32).to(self.device)
-            hit = (tab, off, len(key), tiles, flops, nbytes)
+            bmap = None
+            if GROUP_ORDER and tiles >= GROUP_ORDER_MIN_TILES:
+                bmap = torch.tensor(xcd_block_map([(it[3], it[4], it[5]) for it in key], T, fuse is not None, GROUP_ORDER),
+                                    dtype=torch.int32).to(self.device)
+            hit = (tab, off, len(key), tiles, flops, nbytes, bmap)
             if len(self.cache) > 64:
                 self.cache.clear()
             self.cache[key] = hit
-        tab, off, n, tiles, flops, nbytes = hit
+        tab, off, n, tiles, flops, nbytes, bmap = hit
+        bm_ptr, bm_n = (bmap.data_ptr(), bmap.numel()) if bmap is not None else (None, 0)
         lib = L.load()
         e0 = _prof_begin()
         if fuse is not None:
             L.check("gstvd_gemm_grouped_adamw", lib.gstvd_gemm_grouped_adamw(tab.data_ptr(), off.data_ptr(), n, tiles, C.byref(fuse.desc()),
-                                                                             _stream()))
+                                                                             bm_ptr, bm_n, _stream()))
             if e0 is not None:
                 name = _KNAME.get("grouped_adamw")
                 if name is None:
@@ -336,7 +433,7 @@ class GemmGroup(object):
             self.items = []
             return fused
         L.check("gstvd_gemm_grouped", lib.gstvd_gemm_grouped(tab.data_ptr(), off.data_ptr(), n, tiles, self.dtype_in, self.dtype_out,
-                                                             int(self.a_km), int(self.b_km), _stream()))
+                                                             int(self.a_km), int(self.b_km), bm_ptr, bm_n, _stream()))
         if e0 is not None:
             key = ("grouped", self.dtype_in, self.dtype_out, self.a_km, self.b_km)
             name = _KNAME.get(key)

@@ -218,7 +218,7 @@ class FusedAdamW(object):
         self.opt_step += 1
         self.step_dev.add_(1.0)
 
-    def apply_range(self, lo, hi, grad_bf16=None, fused=()):
+    def apply_range(self, lo, hi, grad_bf16=None, fused=(), grad_origin=None):
         """AdamW on flat elements [lo, hi) -- used slice by slice by the backward pipeline.  `grad_bf16`: the slice's
         gradients as a bf16 tensor of hi-lo elements (the all-reduced compressed copy) instead of G[lo:hi].  `fused`: flat
         offsets of the weights the slice's weight-gradient launch has already updated (ops.GemmGroup.flush(fuse=...)): only the
@@ -232,8 +232,9 @@ class FusedAdamW(object):
                 ops.adamw_blocks(flat.P, flat.G, self.m, self.v, flat.S, self.seg_end, self.hp, self.step_dev, blocks, skip,
                                  self.betas[0], self.betas[1], self.eps, self.grad_scale, begin=lo, end=hi)
         elif grad_bf16 is not None:
+            # grad_bf16[k] is the gradient of flat element grad_origin + k (default: the tensor starts at lo)
             ops.adamw(flat.P, grad_bf16, self.m, self.v, flat.S, self.seg_end, self.hp, self.step_dev, self.betas[0],
-                      self.betas[1], self.eps, self.grad_scale, begin=lo, end=hi, grad_origin=lo)
+                      self.betas[1], self.eps, self.grad_scale, begin=lo, end=hi, grad_origin=lo if grad_origin is None else grad_origin)
         else:
             ops.adamw(flat.P, flat.G, self.m, self.v, flat.S, self.seg_end, self.hp, self.step_dev, self.betas[0],
                       self.betas[1], self.eps, self.grad_scale, begin=lo, end=hi)
@@ -307,6 +308,9 @@ class FusedAdamW(object):
             return dict(self._pending)
         if not self._built:
             return {}
+        pipe = getattr(self.engine, "pipe", None)
+        if pipe is not None and hasattr(pipe, "check_master_current"):
+            pipe.check_master_current("optimizer.state_dict()")
         return dict(m=self.m, v=self.v, opt_step=self._sync_step(), sched_step=self.sched_step)
 
     def load_state_dict(self, sd):
@@ -332,6 +336,9 @@ class FusedAdamW(object):
         `reference_param_index` order, state only for tensors that have received gradients."""
         if not self._ensure_built():
             raise RuntimeError("FusedAdamW before the first forward")
+        pipe = getattr(self.engine, "pipe", None)
+        if pipe is not None and hasattr(pipe, "check_master_current"):
+            pipe.check_master_current("optimizer.export_reference_state()")
         flat = self.engine.flat
         off_of = {id(p): off for p, off in flat.items}
         names = self._names()

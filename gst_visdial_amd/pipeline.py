@@ -24,12 +24,23 @@ import torch
 import torch.distributed as dist
 
 
+SHARD_ALIGN = 1024        # a rank's shard of a slice is a multiple of this many elements (16-byte pieces in every dtype, whole AdamW blocks)
+
+
 class BackwardPipeline(object):
     def __init__(self, engine, optimizer=None, group=None, chunk_elems=40 << 20, compress=None, force_collective=False,
-                 keep_grads=False):
+                 keep_grads=False, shard_update=False):
         self.engine, self.opt, self.group = engine, optimizer, group
         self.chunk = chunk_elems
         self.compress = compress
+        # shard_update (N > 1, optimizer attached): per slice REDUCE-SCATTER the gradients, run AdamW on this rank's 1/N shard only
+        # (fp32 master weights and both moments are current only there), ALL-GATHER the updated bf16 shadow weights (+ the fp32
+        # values of the few parameters the forward reads in fp32).  The reference's optimizer runs once, on GPU 0
+        # (train_gen.py:326-329); the all-reduce path above runs the full 388 M-parameter AdamW on EVERY rank (1.7 ms of HBM
+        # time per step), this one 1/N of it, for the same bytes on the links.  See _run_sharded.
+        self.shard_update = bool(shard_update)
+        self._plans = {}
+        self.master_stale = False     # sharded steps ran since the last sync_master(): fp32 masters / moments of other ranks' shards are old
         # compress="bf16": the slice is cast to bf16, all-reduced, and (with an optimizer attached) consumed by AdamW
         # straight from the bf16 copy; the fp32 buffer G / `.grad` then keeps the LOCAL gradients unless keep_grads
         self.keep_grads = keep_grads
@@ -51,20 +62,37 @@ class BackwardPipeline(object):
         self.fuse_update = os.environ.get("GSTVD_FUSE_UPDATE", "1") != "0"
         if optimizer is not None:
             optimizer.grad_scale = 1.0 / self.world
+        self._skip_next = self._skipping = False
+        self._stale = set()           # flat offsets of the weights whose gradient the LAST backward never stored (fused update)
         engine.pipe = self
+
+    def skip_update_once(self):
+        """The NEXT backward only produces gradients: no all-reduce, no optimizer step, nothing zeroed -- iteration 0 of
+        train_gen.py:326-329 (`if iter_id > 0: optimizer.step(); optimizer.zero_grad()`).  The gradients stay in the flat
+        buffer / `.grad`, LOCAL to the rank; the following backward accumulates onto them (leave `.grad` alone in between, as
+        the reference does) and that sum is what gets all-reduced and applied, once."""
+        self._skip_next = True
 
     def begin(self):
         """Called by the engine at the start of backward (main stream)."""
         self.hi = self.engine.flat.n_live
         self.slices = []
-        if self.opt is not None:
+        self._stale = set()
+        self._skipping, self._skip_next = self._skip_next, False
+        if self.opt is not None and not self._skipping:
             self.opt.begin_step()
 
     def fuse_handle(self):
         """Not None when the slice's weight-gradient launch may update its weights itself (see __init__)."""
-        if self.collective or self.opt is None or not self.fuse_update:
+        if self.collective or self.opt is None or not self.fuse_update or self._skipping:
             return None
         return self.opt.fuse_handle(write_grad=self.keep_grads)
+
+    def stale_grad_offsets(self):
+        """Flat offsets of the tensors whose gradient the backward that just ended did NOT materialise: the weight-gradient
+        launch updated them in its epilogue without storing dW (fuse_update without keep_grads).  The engine leaves their
+        `.grad` at None instead of a view of stale bytes."""
+        return self._stale
 
     def ready(self, off):
         """True when the completed region [off, hi) should be emitted now.  `chunk_elems` may be a sequence: the k-th slice
@@ -86,9 +114,11 @@ class BackwardPipeline(object):
         hipStreamEndCapture on this stack: a forked stream may only be joined into the capture's origin stream.)"""
         flat = self.engine.flat
         self.slices.append((lo, hi))
-        if hi <= lo:
+        if hi <= lo or self._skipping:
             self.hi = lo
             return
+        if fused and not self.keep_grads:
+            self._stale.update(fused)
         sl = flat.G[lo:hi]
         if not self.collective:
             if self.update_stream and sl.is_cuda and self.opt is not None:
@@ -105,6 +135,20 @@ class BackwardPipeline(object):
                     self.tail_event.record(self.comm)
             else:
                 self._update(lo, hi, None, fused)
+        elif self.shard_update and self.opt is not None:
+            if sl.is_cuda and self.use_comm_stream:
+                if self.comm is None:
+                    self.comm = torch.cuda.Stream(device=sl.device)
+                    self._tick = torch.zeros(1, device=sl.device)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                self.comm.wait_event(ev)
+                with torch.cuda.stream(self.comm):
+                    self._run_sharded(lo, hi)
+                    self.tail_event = torch.cuda.Event()
+                    self.tail_event.record(self.comm)
+            else:
+                self._run_sharded(lo, hi)
         elif not sl.is_cuda or not self.use_comm_stream:       # host tensors (gloo tests) / in-line variant
             reduced = None
             if self.compress == "bf16":
@@ -156,9 +200,126 @@ class BackwardPipeline(object):
         if self.opt is not None:
             self.opt.apply_range(lo, hi, grad_bf16=reduced, fused=fused)
 
+    # ---- sharded update -----------------------------------------------------------------------------------------------------
+    def _plan(self, lo, hi):
+        """Static partition of slice [lo, hi) over the ranks (built once per slice, before any hipGraph capture):
+          bulk  = [lo, lo + world * S): rank q owns [lo + q S, lo + (q + 1) S), S a multiple of SHARD_ALIGN -- equal shards, so the
+                  reduce-scatter and both all-gathers are single in-place-shaped collectives on contiguous memory;
+          rest  = [lo + world * S, hi) (< world * SHARD_ALIGN elements): all-reduced and updated by EVERY rank, like the
+                  all-reduce path does for everything.
+        `pack` = positions inside this rank's shard that the forward reads as fp32 (biases, LayerNorm, embedding tables: everything
+        but the GEMM weights, which it reads from the bf16 shadow): their fp32 values travel in a second, small all-gather."""
+        key = (lo, hi)
+        pl = self._plans.get(key)
+        if pl is not None:
+            return pl
+        flat = self.engine.flat
+        dev = flat.G.device
+        if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("BackwardPipeline(shard_update): new slice during a hipGraph capture -- run one eager step first")
+        world = self.world
+        rank = dist.get_rank(self.group)
+        L = hi - lo
+        S = (L // (world * SHARD_ALIGN)) * SHARD_ALIGN
+        bulk = world * S
+        pay = torch.bfloat16 if self.compress == "bf16" else torch.float32
+        pl = dict(S=S, bulk=bulk, rest=L - bulk, a=lo + rank * S, b=lo + (rank + 1) * S)
+        pl["red"] = torch.empty(L, dtype=pay, device=dev) if self.compress == "bf16" else None
+        pl["shard"] = torch.empty(S, dtype=pay, device=dev) if S else None
+        pl["pack"] = None
+        shadow = getattr(flat, "S", None)
+        if S and shadow is not None:
+            ranges = flat.fp32_read_ranges() if hasattr(flat, "fp32_read_ranges") else [(0, flat.n_live)]
+            per_rank = []
+            for q in range(world):
+                a, b = lo + q * S, lo + (q + 1) * S
+                idx = [torch.arange(max(a, x), min(b, y), dtype=torch.int64) for (x, y) in ranges if max(a, x) < min(b, y)]
+                per_rank.append(torch.cat(idx) if idx else torch.zeros(0, dtype=torch.int64))
+            width = max(int(i.numel()) for i in per_rank)
+            if width:
+                mine = per_rank[rank]
+                src = torch.cat([q * width + torch.arange(i.numel(), dtype=torch.int64) for q, i in enumerate(per_rank)])
+                pl["pack"] = dict(width=width, n_mine=int(mine.numel()), mine=mine.to(dev), dst=torch.cat(per_rank).to(dev), src=src.to(dev),
+                                  buf=torch.zeros(width, dtype=torch.float32, device=dev),
+                                  all=torch.empty(world * width, dtype=torch.float32, device=dev))
+        self._plans[key] = pl
+        return pl
+
+    def _run_sharded(self, lo, hi):
+        """One slice of the sharded update, on the current stream: [cast] -> reduce-scatter(bulk) + all-reduce(rest) -> AdamW on
+        (own shard, rest) -> all-gather(bf16 shadow of the bulk) [-> all-gather(fp32-read parameters)].  Link bytes per rank and
+        slice: (N-1)/N x 2 L for the scatter + (N-1)/N x 2 L for the gather = the ring all-reduce's 2 (N-1)/N x 2 L (bf16 payload);
+        update cost L / N instead of L.  Without a bf16 shadow (fp32 precision mode) the fp32 weights are gathered instead."""
+        flat, opt, pl = self.engine.flat, self.opt, self._plan(lo, hi)
+        S, bulk, a, b = pl["S"], pl["bulk"], pl["a"], pl["b"]
+        G = flat.G[lo:hi]
+        if pl["red"] is not None:
+            red = pl["red"]
+            if G.is_cuda:
+                from . import ops
+                ops.cast(G, red)
+            else:
+                red.copy_(G)
+        else:
+            red = G
+            if G.is_cuda and getattr(self, "_tick", None) is not None:
+                self._tick.zero_()               # work of our own in front of the first collective on this stream (see run_slice)
+        if S:
+            dist.reduce_scatter_tensor(pl["shard"], red[:bulk], op=dist.ReduceOp.SUM, group=self.group)
+        if pl["rest"]:
+            dist.all_reduce(red[bulk:], op=dist.ReduceOp.SUM, group=self.group)
+        if red.dtype == torch.bfloat16:
+            if self.keep_grads and S:            # `.grad` of the rank's own shard and of the rest (the only parts it has in full)
+                flat.G[a:b].copy_(pl["shard"]); flat.G[lo + bulk:hi].copy_(red[bulk:])
+            if S:
+                opt.apply_range(a, b, grad_bf16=pl["shard"], grad_origin=a)
+            if pl["rest"]:
+                opt.apply_range(lo + bulk, hi, grad_bf16=red[bulk:], grad_origin=lo + bulk)
+        else:
+            if S:
+                flat.G[a:b].copy_(pl["shard"])   # (the scatter's output cannot alias its input on every backend)
+                opt.apply_range(a, b)
+            if pl["rest"]:
+                opt.apply_range(lo + bulk, hi)
+        if S:
+            self.master_stale = self.world > 1
+            W = flat.S if getattr(flat, "S", None) is not None else flat.P
+            dist.all_gather_into_tensor(W[lo:lo + bulk], W[a:b], group=self.group)
+            pk = pl["pack"]
+            if pk is not None:
+                if pk["n_mine"]:
+                    pk["buf"][:pk["n_mine"]].copy_(flat.P.index_select(0, pk["mine"]))
+                dist.all_gather_into_tensor(pk["all"], pk["buf"], group=self.group)
+                flat.P.index_copy_(0, pk["dst"], pk["all"].index_select(0, pk["src"]))
+
+    def sync_master(self):
+        """After sharded steps the fp32 master weights and the moments of a slice's bulk are current only on their owner.
+        Gathers them (in place, same partition) so that this rank's `state_dict()` / optimizer state / checkpoint is complete
+        (train_gen.py:346-357 saves from one process).  A no-op without shard_update; collective: every rank must call it."""
+        if not (self.shard_update and self.collective and self.opt is not None):
+            return
+        flat, opt = self.engine.flat, self.opt
+        for (lo, hi) in self.slices:
+            pl = self._plans.get((lo, hi))
+            if pl is None or not pl["S"]:
+                continue
+            a, b, bulk = pl["a"], pl["b"], pl["bulk"]
+            for buf in (flat.P, opt.m, opt.v):
+                dist.all_gather_into_tensor(buf[lo:lo + bulk], buf[a:b].clone(), group=self.group)
+        self.master_stale = False
+
+    def check_master_current(self, what):
+        """state_dict() / checkpoint guard: a COLLECTIVE must not hide inside a call that train_gen.py:346-357 makes on one process
+        only, so a stale master copy is an error with the way out in the message, never a silent gather or a silent stale file."""
+        if self.master_stale:
+            from ._lib import GstvdError
+            raise GstvdError("%s while the optimizer is sharded over %d ranks: this rank holds current fp32 master weights / moments only "
+                             "for its own shards.  Call pipe.sync_master() on EVERY rank first (one all-gather per slice), then save "
+                             "from whichever rank you like." % (what, self.world))
+
     def end(self):
         """End of backward.  Returns the event the caller's stream must wait on (the communication stream's last work) or None."""
-        if self.opt is not None:
+        if self.opt is not None and not self._skipping:
             self.opt._applied_in_backward = True
         ev, self.tail_event = self.tail_event, None
         return ev

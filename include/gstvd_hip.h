@@ -85,13 +85,20 @@ int64_t gstvd_gemm_splitk_ws_bytes(int64_t M, int64_t N, int32_t splits);
 int gstvd_gemm_splitk(const gstvd_gemm_t* g, int32_t splits, void* ws, int64_t ws_bytes, gstvd_stream_t s);
 
 /* Grouped form: `table_dev` is a DEVICE array of nprob independent problems (batch ignored, = 1) that share dtypes
- * and operand layouts; they run as ONE launch over all their 128x128 tiles.  tile_off_dev[i] = first tile id of
- * problem i (ceil(M/128)*ceil(N/128) tiles each), device int32[nprob].  The engine uses it for the deferred
- * weight-gradient GEMMs of a whole backward pass (dW = dy^T x: a_kmajor = b_kmajor = 1, fp32 out, EPI_ADD to
- * accumulate), whose individual grids are too small to fill the chip.  bf16 inputs only. */
+ * and operand layouts; they run as ONE launch over all their T x T tiles, T = gstvd_gemm_group_tile() (256).
+ * tile_off_dev[i] = first tile id of problem i (ceil(M/T)*ceil(N/T) tiles each), device int32[nprob].  The engine uses it
+ * for the deferred weight-gradient GEMMs of a whole backward pass (dW = dy^T x: a_kmajor = b_kmajor = 1, fp32 out, EPI_ADD
+ * to accumulate), whose individual grids are too small to fill the chip.  bf16 inputs only.
+ * block_map_dev (ABI 5; NULL = the library's own order): device int32[nblocks], nblocks >= total_tiles -- workgroup b runs
+ * tile block_map_dev[b] (a tile id as in tile_off_dev), or nothing when the entry is negative; every tile id must appear
+ * exactly once.  Workgroups b, b + 8, b + 16, ... share one XCD and its L2 (a speed fact, never a correctness one): the
+ * caller that knows which problems share operand panels and run equally long (same K) queues them back to back on one XCD,
+ * so that the ~32 tiles an XCD runs at a time stream the same panels in step -- autograd has no counterpart, it is pure
+ * placement. */
 int gstvd_gemm_group_tile(void);
 int gstvd_gemm_grouped(const gstvd_gemm_t* table_dev, const int32_t* tile_off_dev, int64_t nprob, int64_t total_tiles,
-                       int32_t dtype_in, int32_t dtype_out, int32_t a_kmajor, int32_t b_kmajor, gstvd_stream_t s);
+                       int32_t dtype_in, int32_t dtype_out, int32_t a_kmajor, int32_t b_kmajor,
+                       const int32_t* block_map_dev, int64_t nblocks, gstvd_stream_t s);
 
 /* ---- fused (bias-free) dropout + residual + LayerNorm, and the two embedding front ends -----
  * mode GSTVD_LN_RESID : h = drop_pre(x) + res ; y = drop_post(LN(h))   (BertSelfOutput/BertOutput/
@@ -301,7 +308,7 @@ typedef struct {
   int32_t write_grad;
 } gstvd_adamw_fuse_t;
 int gstvd_gemm_grouped_adamw(const gstvd_gemm_t* table_dev, const int32_t* tile_off_dev, int64_t nprob, int64_t total_tiles,
-                             const gstvd_adamw_fuse_t* f, gstvd_stream_t s);
+                             const gstvd_adamw_fuse_t* f, const int32_t* block_map_dev, int64_t nblocks, gstvd_stream_t s);
 /* measurement support: the (mangled) symbol of the kernel gstvd_gemm_grouped_adamw launches (rocprofv3 traces key on it) */
 int gstvd_gemm_grouped_adamw_kernel_name(char* buf, int32_t buf_len);
 

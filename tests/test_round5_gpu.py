@@ -1,0 +1,246 @@
+"""Round 5 on the GPU: the XCD placement of the grouped weight-gradient launch (results must not depend on it), the tied
+decoder embedding (a second writer into a weight's gradient slot), `.grad` of weights the launch updated itself,
+pipe.skip_update_once() (train_gen.py:326-329, iteration 0) and AdamW's fast square root / reciprocal against the IEEE sequence."""
+import os
+import sys
+
+import pytest
+import torch
+
+from conftest import load_npz
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def sc():
+    from gst_visdial_amd import selfcheck
+    return selfcheck
+
+
+# ---- placement --------------------------------------------------------------------------------------------------------------
+SHAPES = [(768, 768, 400), (3072, 768, 1000), (300, 64, 37), (1024, 1024, 592), (768, 3072, 400), (2304, 768, 1024), (520, 196, 100),
+          (768, 768, 1000), (3072, 768, 400), (256, 256, 400), (1024, 2048, 592), (64, 3072, 256), (768, 1024, 1000)]
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_grouped_launch_results_do_not_depend_on_the_block_map(mode, monkeypatch):
+    """gstvd_gemm_grouped with block_map_dev: every tile of every problem runs exactly once whatever the order -- dW and the bias
+    column sums are bit-identical to the library's own order (same per-tile arithmetic), incl. ragged shapes and idle blocks."""
+    from gst_visdial_amd import ops
+    g = torch.Generator().manual_seed(3)
+    dys = [(torch.randn(K, M, generator=g) * 0.1).to(DEV).bfloat16() for M, N, K in SHAPES]
+    xs = [torch.randn(K, N, generator=g).to(DEV).bfloat16() for M, N, K in SHAPES]
+
+    def run(order):
+        monkeypatch.setattr(ops, "GROUP_ORDER", order)
+        monkeypatch.setattr(ops, "GROUP_ORDER_MIN_TILES", 0)
+        grp = ops.GemmGroup(torch.device(DEV), a_km=True, b_km=True)
+        outs = [torch.full((M, N), 7.0, device=DEV) for M, N, K in SHAPES]
+        biases = [torch.zeros(M, device=DEV) for M, N, K in SHAPES]
+        for i, ((M, N, K), dy, x) in enumerate(zip(SHAPES, dys, xs)):
+            grp.add(dy, x, outs[i], M, N, K, i % 4 == 3, colsum_out=biases[i] if grp.colsum_capable(dy) else None)
+        grp.flush()
+        torch.cuda.synchronize()
+        hit = list(grp.cache.values())[0]
+        return outs, biases, hit[6]
+
+    ref_o, ref_b, bm0 = run(0)
+    got_o, got_b, bm = run(mode)
+    assert bm0 is None and bm is not None and int((bm >= 0).sum()) == sum(((M + 255) // 256) * ((N + 255) // 256) for M, N, K in SHAPES)
+    assert int((bm < 0).sum()) > 0                              # the queues of this table are ragged: idle blocks are exercised
+    for (M, N, K), a, b, dy, x in zip(SHAPES, ref_o, got_o, dys, xs):
+        assert torch.equal(a, b), (M, N, K)
+    for a, b in zip(ref_b, got_b):
+        assert torch.equal(a, b)
+    want = dys[1].float().t() @ xs[1].float()
+    assert (got_o[1] - want).abs().max().item() < 2e-2 * want.abs().max().item()
+
+
+def test_bad_block_map_is_rejected():
+    from gst_visdial_amd import _lib as L
+    lib = L.load()
+    z = torch.zeros(64, dtype=torch.int32, device=DEV)
+    tab = torch.zeros(512, dtype=torch.uint8, device=DEV)
+    rc = lib.gstvd_gemm_grouped(tab.data_ptr(), z.data_ptr(), 1, 9, L.BF16, L.F32, 1, 1, z.data_ptr(), 8, None)
+    assert rc == -2                                             # GSTVD_E_SHAPE: a map shorter than the tile count
+
+
+# ---- the tied LM head: two writers into one gradient slot ----------------------------------------------------------------------
+def _untied_vs_tied_models(precision):
+    """The golden tiny model WITHOUT train_gen.py:293: the decoder keeps its own embedding module, whose word table IS the LM
+    head's weight (visual_dialog_decoder.py:329-335)."""
+    import json
+    import tempfile
+    from gst_visdial_amd.modules import VisualDialogEncoder, VisualDialogDecoder, EncoderDecoderModel
+    cfg = json.load(open(os.path.join(ROOT, "tests", "golden", "tiny_cfg.json")))
+    d = tempfile.mkdtemp(prefix="gstvd_cfg_")
+    json.dump(cfg["enc"], open(d + "/e.json", "w"))
+    json.dump(cfg["dec"], open(d + "/d.json", "w"))
+    params = dict(model_enc_config=d + "/e.json", model_dec_config=d + "/d.json", gpu_ids=[0], model="enc_dec_a", mode="vd_train",
+                  batch_size=3, device=torch.device(DEV), amd_precision=precision, amd_seed=0)
+    enc, dec = VisualDialogEncoder(params), VisualDialogDecoder(params)
+    model = EncoderDecoderModel(params, enc, dec)
+    sd = load_npz("tiny_state.npz")
+    g = torch.Generator().manual_seed(11)
+    # the fixture was written with shared embeddings: give the decoder's own module values of its own, tie the LM head to its table
+    for k in list(sd):
+        if k.startswith("decoder.decoder.bert.embeddings.") and "LayerNorm" not in k:
+            sd[k] = sd[k] + 0.05 * torch.randn(sd[k].shape, generator=g)
+    sd["decoder.decoder.lm_head.decoder.weight"] = sd["decoder.decoder.bert.embeddings.word_embeddings.weight"]
+    model.load_state_dict(sd, strict=True)
+    return model.to(DEV), sd, cfg
+
+
+@pytest.mark.parametrize("with_pipeline", [False, True], ids=["plain_backward", "pipeline_fused_update"])
+def test_tied_lm_head_gradient_has_both_contributions(with_pipeline):
+    """with the LM head tied to the decoder's own word embedding the table's gradient slot has TWO writers -- the
+    LM-head weight-gradient GEMM (queued, launched later) and the embedding scatter-add.  Both must arrive, and a fused update
+    must not be applied to that weight from the GEMM's accumulators alone."""
+    from oracle import vd_oracle as O
+    from gst_visdial_amd.optim import FusedAdamW
+    from gst_visdial_amd.pipeline import BackwardPipeline
+    model, sd, cfg = _untied_vs_tied_models("fp32")
+    model.eval()
+    g = load_npz("tiny_train.npz")
+    eng = model.engine
+    if with_pipeline:
+        opt = FusedAdamW(model, lr=1e-3)
+        pipe = BackwardPipeline(eng, optimizer=opt, chunk_elems=1 << 40, keep_grads=True)
+    loss, logits = model(**sc().golden_batch(g, DEV))
+    p_before = None
+    if with_pipeline:
+        eng.prepare(torch.device(DEV))
+        p_before = eng.flat.P.clone()
+    loss.backward()
+    torch.cuda.synchronize()
+    # oracle with the tie restored by hand: one tensor behind both keys
+    osd = {k: v.clone() for k, v in sd.items()}
+    wkey, lkey = "decoder.decoder.bert.embeddings.word_embeddings.weight", "decoder.decoder.lm_head.decoder.weight"
+    tied = osd[wkey].clone().requires_grad_(True)
+    osd[wkey] = osd[lkey] = tied
+    osd["decoder.decoder.lm_head.decoder.bias"] = osd["decoder.decoder.lm_head.bias"]
+    b = {k[4:]: v.clone() for k, v in g.items() if k.startswith("in::")}
+    ref = O.model_forward(osd, cfg["enc"], cfg["dec"], b)
+    ref["loss"].backward()
+    assert abs(loss.item() - ref["loss"].item()) < 1e-5
+    w = model.decoder.decoder.lm_head.decoder.weight
+    assert w is model.decoder.decoder.bert.embeddings.word_embeddings.weight
+    got = w.grad.float().cpu()
+    want = tied.grad
+    lm_only = want.clone()
+    err = (got - want).abs().max().item()
+    assert err < 2e-4 * want.abs().max().item() + 1e-7, err
+    # the embedding rows of the decoder's input ids carry the scatter-add part: it must be there (a lost contribution shows here)
+    ids = b["dec_input_ids"].reshape(-1).unique()
+    assert (got[ids] - want[ids]).abs().max().item() < 2e-4 * want.abs().max().item() + 1e-7
+    if with_pipeline:
+        off = eng.flat.slots["lm.w"][0]
+        n = want.numel()
+        assert eng.flat.slots["lm.w"] == eng.flat.slots["demb.word"]
+        # the update that WAS applied used the full gradient: compare with a plain AdamW step on the oracle gradient
+        m = 0.1 * want
+        v = 0.001 * want * want
+        upd = p_before[off:off + n].cpu().view_as(want) - 1e-3 * ((1 - 0.999) ** 0.5 / (1 - 0.9)) * m / (v.sqrt() + 1e-6)
+        upd = upd * (1 - 1e-3 * 0.01)
+        now = eng.flat.P[off:off + n].cpu().view_as(want)
+        assert (now - upd).abs().max().item() < 5e-6
+
+
+# ---- .grad of weights the launch updated itself ------------------------------------------------------------------------------
+def test_fused_weights_have_no_stale_grad_and_keep_grads_materialises_them():
+    from gst_visdial_amd.optim import FusedAdamW
+    from gst_visdial_amd.pipeline import BackwardPipeline
+    g = load_npz("tiny_train.npz")
+    for keep in (False, True):
+        model, params, cfg = sc().build_tiny_model("bf16", DEV, seed=2)
+        model.train()
+        opt = FusedAdamW(model, lr=1e-3)
+        pipe = BackwardPipeline(model.engine, optimizer=opt, chunk_elems=1 << 40, keep_grads=keep)
+        for _ in range(2):
+            loss, _ = model(**sc().golden_batch(g, DEV))
+            loss.backward()
+            opt.step()
+            w = model.encoder.bert_pretrained.bert.encoder.layer[0].intermediate.dense.weight
+            b = model.encoder.bert_pretrained.bert.encoder.layer[0].intermediate.dense.bias
+            assert pipe.fuse_handle() is not None
+            assert b.grad is not None and torch.isfinite(b.grad).all()
+            if keep:
+                assert w.grad is not None and w.grad.abs().sum().item() > 0
+            else:
+                assert w.grad is None                    # updated in the launch's epilogue, dW never stored: nothing stale to read
+            opt.zero_grad()
+
+
+# ---- iteration 0 of train_gen.py ------------------------------------------------------------------------------------------------
+def test_skip_update_once_reproduces_the_reference_loops_first_iterations():
+    """train_gen.py:324-329: `if iter_id > 0: optimizer.step(); optimizer.zero_grad()` -- iteration 0's gradients are neither applied
+    nor zeroed and add to iteration 1's.  BackwardPipeline applies its update inside backward(); pipe.skip_update_once() makes
+    the pipelined loop equal the plain FusedAdamW loop (which reproduces the reference's own 6-iteration run, test_round2_gpu)."""
+    from gst_visdial_amd.optim import FusedAdamW
+    from gst_visdial_amd.pipeline import BackwardPipeline
+    g = load_npz("tiny_train.npz")
+
+    def run(pipelined):
+        model, params, cfg = sc().build_tiny_model("fp32", DEV, seed=1)
+        model.eval()                                         # (dropout off: the two loops must agree to rounding)
+        opt = FusedAdamW(model, lr=2e-3, warmup_steps=2, t_total=20)
+        pipe = BackwardPipeline(model.engine, optimizer=opt, chunk_elems=60000) if pipelined else None
+        losses = []
+        for it in range(4):
+            if pipelined and it == 0:
+                pipe.skip_update_once()
+            loss, _ = model(**sc().golden_batch(g, DEV))
+            loss.backward()
+            if it > 0:
+                opt.step()
+                opt.zero_grad()
+            opt.scheduler_step()
+            losses.append(loss.item())
+        torch.cuda.synchronize()
+        return losses, model.engine.flat.P.detach().cpu().clone(), opt._sync_step()
+
+    l0, p0, s0 = run(False)
+    l1, p1, s1 = run(True)
+    assert s0 == s1 == 3
+    assert l0[0] == l0[1] and l1[0] == l1[1]                 # nothing moved at iteration 0
+    assert max(abs(a - b) for a, b in zip(l0, l1)) < 1e-5
+    assert (p0 - p1).abs().max().item() < 5e-6
+
+
+# ---- AdamW arithmetic ---------------------------------------------------------------------------------------------------------
+def test_adamw_fast_sqrt_rcp_against_ieee_incl_tiny_second_moments():
+    """adamw_update4 uses the hardware's ~1-ulp v_sqrt_f32 / v_rcp_f32 (shared with the weight-gradient launch's
+    epilogue, with which it must agree bit for bit) instead of the IEEE sqrt / divide of pytorch_transformers' AdamW
+    (exp_avg / (exp_avg_sq.sqrt() + eps)).  The deviation stays at the last bits of the UPDATE TERM -- which lr then scales to
+    ~1e-9 of a weight -- also where the second moment is tiny or subnormal (v_sqrt_f32 does not take denormals)."""
+    from gst_visdial_amd import ops
+    n = 1 << 16
+    g = torch.Generator().manual_seed(1)
+    P = torch.randn(n, generator=g)
+    P[::2] = 0.0                                                                               # (there the new weight IS the update term)
+    grad = torch.randn(n, generator=g) * 10.0 ** (torch.rand(n, generator=g) * 30 - 28)       # gradients from 1e-28 to 100
+    M = torch.zeros(n); V = torch.zeros(n)
+    V[: n // 4] = 10.0 ** (torch.rand(n // 4, generator=g) * 20 - 44)                          # old second moments down to subnormal
+    lr, wd, b1, b2, eps, t = 1e-3, 0.01, 0.9, 0.999, 1e-6, 5.0
+    seg_end = torch.tensor([n], dtype=torch.int64, device=DEV)
+    hp = torch.tensor([lr, wd], device=DEV)
+    step = torch.full((1,), t, device=DEV)
+    Pd, Gd, Md, Vd = P.to(DEV), grad.to(DEV), M.to(DEV), V.to(DEV)
+    Sd = torch.zeros(n, dtype=torch.bfloat16, device=DEV)
+    ops.adamw(Pd, Gd, Md, Vd, Sd, seg_end, hp, step, b1, b2, eps, 1.0)
+    torch.cuda.synchronize()
+    m = M.double() * b1 + grad.double() * (1 - b1)
+    v = V.double() * b2 + grad.double() ** 2 * (1 - b2)
+    bc = (1 - b2 ** t) ** 0.5 / (1 - b1 ** t)
+    term = m / (v.sqrt() + eps)
+    p = (P.double() - lr * bc * term) * (1 - lr * wd)
+    assert torch.isfinite(Pd).all() and torch.isfinite(Vd).all()
+    assert (Md.cpu().double() - m).abs().max().item() <= 1e-6 * m.abs().max().item()
+    assert ((Vd.cpu().double() - v).abs() <= 1e-6 * v + 1e-45).all()
+    got = Pd.cpu().double()
+    assert (got - p).abs().max().item() < 6e-7                                                 # one fp32 ulp of a weight of magnitude 4
+    z = got[::2], p[::2]                                                                      # zero weights: p' = -lr bc term (1 - lr wd)
+    rel = (z[0] - z[1]).abs() / (z[1].abs() + 1e-30)
+    assert rel[z[1].abs() > 1e-20].max().item() < 2e-6                                         # the fast sqrt / rcp cost the TERM a few ulp, no more

@@ -95,7 +95,7 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1, em; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventCreate(&em);
   const float b1 = 0.9f, b2 = 0.999f, eps = 1e-6f, gs = 1.f;
   auto plain = [&](int c) {
-    int rc = gstvd_gemm_grouped(tab_d, toff_d, np, tiles, GSTVD_BF16, GSTVD_F32, 1, 1, s0);
+    int rc = gstvd_gemm_grouped(tab_d, toff_d, np, tiles, GSTVD_BF16, GSTVD_F32, 1, 1, nullptr, 0, s0);
     (void)hipEventRecord(em, s0);
     rc |= gstvd_adamw(P[c], G, Mo[c], V[c], S[c], n, seg_d, hp_d, nseg, b1, b2, eps, step, gs, 0, s0);
     return rc;
@@ -104,7 +104,7 @@ int main(int argc, char** argv) {
     gstvd_adamw_fuse_t f; memset(&f, 0, sizeof(f));
     f.grad_base = G; f.param = P[c]; f.m = Mo[c]; f.v = V[c]; f.shadow_bf16 = S[c]; f.step = step;
     f.beta1 = b1; f.beta2 = b2; f.eps = eps; f.grad_scale = gs; f.write_grad = 0;
-    int rc = gstvd_gemm_grouped_adamw(tabf_d, toff_d, np, tiles, &f, s0);
+    int rc = gstvd_gemm_grouped_adamw(tabf_d, toff_d, np, tiles, &f, nullptr, 0, s0);
     (void)hipEventRecord(em, s0);
     rc |= gstvd_adamw_blocks(P[c], G, Mo[c], V[c], S[c], n, seg_d, hp_d, nseg, b1, b2, eps, step, gs, 0, blocks_d, (int64_t)blocks.size(), skip_d, s0);
     return rc;
