@@ -58,7 +58,9 @@ class AttnDesc(C.Structure):
 
 class SampleDesc(C.Structure):
     _fields_ = [("logits", _vp), ("ld", _i64), ("dtype", _i32), ("B", _i32), ("V", _i32), ("top_k", _i32), ("temperature", _f32),
-                ("u", _vp), ("out", _vp), ("out_stride", _i64), ("banned", _vp), ("banned_ld", _i64)]
+                ("u", _vp), ("out", _vp), ("out_stride", _i64), ("banned", _vp), ("banned_ld", _i64),
+                ("hist", _vp), ("hist_ld", _i64), ("hist_T", _i32), ("ngram", _i32),
+                ("ids_tm", _vp), ("ids_stride", _i64), ("cur_len", _i32), ("n_special", _i32), ("special", _i32 * 8)]
 
 
 class AdamFuse(C.Structure):

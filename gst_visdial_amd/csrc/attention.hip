@@ -24,6 +24,7 @@
 //   * fp32 parity mode runs the same skeleton on v_mfma_f32_16x16x4_f32.
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 #include <type_traits>
 
 template <typename T, int D> struct Img {
@@ -743,6 +744,195 @@ DEVFN void attn_bwd_dkv_body(const gstvd_attn_t& a, const int bx, char* smem) {
   }
 }
 
+// =====================================================================================================
+// backward in ONE pass: bf16, d = 64, up to 256 keys, no causal mask (the text self-attention, vilbert_dialog.py:389-405)
+// =====================================================================================================
+// The two-part backward above computes S = Q K^T, dP = dO V^T, the exponentials and the dropout draws TWICE -- once in the blocks
+// that own queries (dQ) and once in the blocks that own keys (dK, dV): 7 products and 2 x the element-wise work for 5 products'
+// worth of results, and at L = 256 that element-wise work (exp, the counter hash, packing) is what the kernel is made of.
+// Here ONE workgroup owns a (batch row, head): 16 waves x 16 keys.  A wave keeps the K and V rows of its keys as register
+// fragments and dK^T / dV^T of its keys in accumulators (no sum across waves), and walks the queries in chunks of 64 exactly like
+// attn_bwd_dkv_body (same lane layout, same pair-shared dropout draws).  What is new: the wave also writes its dS tile -- key on
+// the row, four consecutive queries per lane -- into an LDS image [256 keys][64 queries]; after a barrier the 16 waves each take
+// one 16 (d) x 16 (query) tile of dQ^T = K^T dS^T for the chunk (A = transposed reads of the resident K image, B = transposed
+// reads of the dS image, 8 MFMAs deep) and store it: dS crosses LDS once, dQ needs no atomics and no second launch.
+// LDS: Q and dO chunk images (row + transposed-read, 4 x 8 KB), K (32 KB), dS (32 KB), LSE / delta of all queries (8 KB): 104 KB;
+// one workgroup per CU.
+constexpr int ONEPASS_MAX_LQ = 1024;
+template <bool E32>
+__global__ __launch_bounds__(1024) void attn_bwd_onepass_kernel(gstvd_attn_t a) {
+  typedef bf16 T;
+  constexpr int D = 64, IB = Img<T, D>::BYTES, TP = 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sQr = smem;
+  char* sQt = smem + IB;
+  char* sOr = smem + 2 * IB;
+  char* sOt = smem + 3 * IB;
+  char* sKt = smem + 4 * IB;                                  // [256 keys][64 d], transposed-read image
+  char* sDs = smem + 8 * IB;                                  // [256 keys][64 queries of the chunk], transposed-read image
+  float* sLse = (float*)(smem + 12 * IB);                     // [ONEPASS_MAX_LQ] LSE of every query (+inf past the end)
+  float* sDel = sLse + ONEPASS_MAX_LQ;                        // [ONEPASS_MAX_LQ] delta of every query
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int key = wave * 16 + li;
+  const bool kv = key < a.Lk;
+  const T* Ob = (const T*)a.O + (int64_t)b * a.Lq * a.ldo + h * D;
+  const T* Qb = (const T*)a.Q + (int64_t)b * a.Lq * a.ldq + h * D;
+  const T* Kb = (const T*)a.K + (int64_t)b * a.Lk * a.ldk + h * D;
+  const T* Vb = (const T*)a.V + (int64_t)b * a.Lk * a.ldv + h * D;
+  const T* dOb = (const T*)a.dO + (int64_t)b * a.Lq * a.lddo + h * D;
+  RowFrag<T, D> kf, vf;
+  kf.load(Kb + (int64_t)key * a.ldk, kv, g);
+  vf.load(Vb + (int64_t)key * a.ldv, kv, g);
+  const bool kmasked = kv && a.key_mask != nullptr && a.key_mask[(int64_t)b * a.Lk + key] == 0.f;
+  const float kadd = kv ? (kmasked ? a.mask_neg : 0.f) : -INFINITY;
+  const DropKey dk = make_drop(a.dropout_p, a.site, a.rng);
+  const int Lkp = round4(a.Lk);
+  const int64_t stat0 = ((int64_t)b * a.nh + h) * a.Lq;
+  const uint64_t half = (uint64_t)(Lkp >> 1);
+  const uint64_t e2lane = ((uint64_t)stat0 + (uint64_t)(4 * g)) * half + (uint64_t)(key >> 1);
+  const bool odd = (key & 1) != 0;
+  // the K image for the dQ product: all (up to 256) keys, rows past the end zero
+#pragma unroll
+  for (int v = tid; v < 256 * 8; v += 1024) {
+    const int row = v >> 3, cv = v & 7;
+    u32x4 z = {0u, 0u, 0u, 0u};
+    if (row < a.Lk) z = *(const u32x4*)(Kb + (int64_t)row * a.ldk + cv * 8);
+    *(u32x4*)(sKt + Img<T, D>::tr_off(row, cv * 8)) = z;
+  }
+
+  f32x4 accK[D / 16], accV[D / 16];
+#pragma unroll
+  for (int i = 0; i < D / 16; ++i) accK[i] = accV[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // delta = rowsum(dO * O) and LSE of ALL queries once, in the prologue (four threads per query row; the loads sit beside the K / V
+  // loads above): the chunk loop below then carries no global-memory result that arithmetic has to wait for
+  for (int q0 = 0; q0 < a.Lq; q0 += 256) {
+    const int qq = q0 + (tid >> 2), part = tid & 3;
+    float dsum = 0.f;
+    if (qq < a.Lq) {
+      const T* dr = dOb + (int64_t)qq * a.lddo + part * (D / 4);
+      const T* orow = Ob + (int64_t)qq * a.ldo + part * (D / 4);
+      const bf16x8 x0 = *(const bf16x8*)dr, x1 = *(const bf16x8*)(dr + 8), y0 = *(const bf16x8*)orow, y1 = *(const bf16x8*)(orow + 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dsum += (float)x0[e] * (float)y0[e] + (float)x1[e] * (float)y1[e];
+    }
+    dsum += __shfl_xor(dsum, 1, 64);
+    dsum += __shfl_xor(dsum, 2, 64);
+    if (part == 0 && qq < a.Lq) {
+      sDel[qq] = dsum;
+      if (a.delta) a.delta[stat0 + qq] = dsum;
+    }
+  }
+  const int Lq64 = (a.Lq + 63) & ~63;
+  for (int q = tid; q < Lq64; q += 1024) {
+    sLse[q] = q < a.Lq ? a.LSE[stat0 + q] : INFINITY;         // +inf => p = 0 for padded query rows
+    if (q >= a.Lq) sDel[q] = 0.f;
+  }
+  // staging of a 64-query chunk: threads [0, 512) carry one 16-byte piece of Q each, threads [512, 1024) one of dO
+  u32x4 pv4 = {0u, 0u, 0u, 0u};
+  const bool is_q = tid < 512;
+  const int sidx = is_q ? tid : tid - 512, srow = sidx >> 3, scv = sidx & 7;
+  auto prefetch = [&](int c0) {
+    pv4 = (u32x4){0u, 0u, 0u, 0u};
+    if (c0 + srow < a.Lq) pv4 = is_q ? *(const u32x4*)(Qb + (int64_t)(c0 + srow) * a.ldq + scv * 8)
+                                     : *(const u32x4*)(dOb + (int64_t)(c0 + srow) * a.lddo + scv * 8);
+  };
+  prefetch(0);
+  const int nkb = (a.Lk + 31) >> 5;                           // 32-key blocks of the dQ contraction
+  const int dq_i = wave & 3, dq_t = wave >> 2;                // this wave's tile of dQ^T: d block, query block of the chunk
+  for (int c0 = 0; c0 < a.Lq; c0 += 64) {
+    __syncthreads();                                          // the previous chunk's images (Q, dO, dS) are no longer read
+    if (is_q) {
+      *(u32x4*)(sQr + Img<T, D>::row_off(srow, scv)) = pv4;
+      *(u32x4*)(sQt + Img<T, D>::tr_off(srow, scv * 8)) = pv4;
+    } else {
+      *(u32x4*)(sOr + Img<T, D>::row_off(srow, scv)) = pv4;
+      *(u32x4*)(sOt + Img<T, D>::tr_off(srow, scv * 8)) = pv4;
+    }
+    __syncthreads();
+    if (c0 + 64 < a.Lq) prefetch(c0 + 64);
+    const uint64_t e2chunk = e2lane + (uint64_t)c0 * half;
+#pragma unroll 1
+    for (int pr = 0; pr < 4 / TP; ++pr) {
+      f32x4 s[TP], dp[TP];
+      float pd[TP][4], ds[TP][4];
+#pragma unroll
+      for (int tt = 0; tt < TP; ++tt) {
+        s[tt] = first_product<T, D>(sQr, 16 * TP * pr + tt * 16, kf, lane);       // [q = 4g + r][key = li]
+        dp[tt] = first_product<T, D>(sOr, 16 * TP * pr + tt * 16, vf, lane);
+      }
+#pragma unroll
+      for (int tt = 0; tt < TP; ++tt) {
+        const int q0 = 16 * TP * pr + tt * 16;
+        const f32x4 lse4 = *(const f32x4*)(sLse + c0 + q0 + 4 * g);
+        const f32x4 del4 = *(const f32x4*)(sDel + c0 + q0 + 4 * g);
+        float f[4] = {1.f, 1.f, 1.f, 1.f};
+        if (dk.on) {      // the two keys of a draw's pair sit in neighbouring lanes: each lane draws for two rows, one quad permute swaps
+          const int r0 = odd ? 2 : 0;
+          const uint32_t mine0 = draw_pair<E32>(dk, e2chunk + (uint64_t)(q0 + r0) * half);
+          const uint32_t mine1 = draw_pair<E32>(dk, e2chunk + (uint64_t)(q0 + r0 + 1) * half);
+          const uint32_t other0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine0, 0xB1, 0xf, 0xf, true);
+          const uint32_t other1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine1, 0xB1, 0xf, 0xf, true);
+          const uint32_t d0 = odd ? other0 : mine0, d1 = odd ? other1 : mine1, d2 = odd ? mine0 : other0, d3 = odd ? mine1 : other1;
+          const uint32_t sh = odd ? 16u : 0u;
+          f[0] = ((d0 >> sh) & 0xffffu) >= dk.thr ? dk.scale : 0.f;
+          f[1] = ((d1 >> sh) & 0xffffu) >= dk.thr ? dk.scale : 0.f;
+          f[2] = ((d2 >> sh) & 0xffffu) >= dk.thr ? dk.scale : 0.f;
+          f[3] = ((d3 >> sh) & 0xffffu) >= dk.thr ? dk.scale : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __expf(s[tt][r] * a.scale + kadd - lse4[r]);
+          pd[tt][r] = p * f[r];
+          ds[tt][r] = p * (dp[tt][r] * f[r] - del4[r]) * a.scale;
+        }
+        // dS^T for the dQ product: row = this lane's key, four consecutive queries (zero for keys / queries past the end: p = 0)
+        *(s16x4*)(sDs + Img<T, D>::tr_off(key, q0 + 4 * g)) = pack_bf16x4(ds[tt][0], ds[tt][1], ds[tt][2], ds[tt][3]);
+      }
+      second_product_pair<T, D>(accV, sOt, 16 * TP * pr, pd[0], pd[1], lane);
+      second_product_pair<T, D>(accK, sQt, 16 * TP * pr, ds[0], ds[1], lane);
+    }
+    __syncthreads();                                          // the chunk's dS is complete
+    {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      typedef __attribute__((ext_vector_type(8))) short s16x8;
+      const int rr = 4 * g + (li >> 2), cc = 4 * (lane & 3);
+      // two 32-key blocks at a time: their eight transposed reads are in flight together, then two MFMAs (rows past the last
+      // key are zero in both images, so a partial group needs no test)
+      for (int kb0 = 0; kb0 < nkb; kb0 += 2) {
+        s16x4 alo[2], ahi[2], blo[2], bhi[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int kb = kb0 + u;
+          alo[u] = lds_tr16(sKt + Img<T, D>::tr_off(32 * kb + rr, dq_i * 16 + cc));
+          ahi[u] = lds_tr16(sKt + Img<T, D>::tr_off(32 * kb + 16 + rr, dq_i * 16 + cc));
+          blo[u] = lds_tr16(sDs + Img<T, D>::tr_off(32 * kb + rr, dq_t * 16 + cc));
+          bhi[u] = lds_tr16(sDs + Img<T, D>::tr_off(32 * kb + 16 + rr, dq_t * 16 + cc));
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const s16x8 av = {alo[u][0], alo[u][1], alo[u][2], alo[u][3], ahi[u][0], ahi[u][1], ahi[u][2], ahi[u][3]};
+          const s16x8 bv = {blo[u][0], blo[u][1], blo[u][2], blo[u][3], bhi[u][0], bhi[u][1], bhi[u][2], bhi[u][3]};
+          acc = mfma_bf16_k32(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc);
+        }
+      }
+      const int q = c0 + dq_t * 16 + li;                      // acc: rows d = 16 dq_i + 4g + r, column = query li
+      if (q < a.Lq) st4((T*)a.dQ + ((int64_t)b * a.Lq + q) * a.lddq + h * D + dq_i * 16 + 4 * g, acc);
+    }
+  }
+  if (kv) {
+    T* dKp = (T*)a.dK + ((int64_t)b * a.Lk + key) * a.lddk + h * D;
+    T* dVp = (T*)a.dV + ((int64_t)b * a.Lk + key) * a.lddv + h * D;
+#pragma unroll
+    for (int i = 0; i < D / 16; ++i) {
+      st4(dKp + i * 16 + 4 * g, accK[i]);
+      st4(dVp + i * 16 + 4 * g, accV[i]);
+    }
+  }
+}
+
 // ---- host side ---------------------------------------------------------------------------------------
 template <typename K> static int attn_lds_attr(K kernel, int bytes) {
   if (bytes <= 48 * 1024) return 0;
@@ -798,8 +988,27 @@ __global__ __launch_bounds__(256, (D <= 64 ? 3 : 2)) void attn_bwd_kernel(gstvd_
   else attn_bwd_dq_body<T, D, false>(a, bx - nkb, smem);
 }
 
+static bool attn_small_index_space_host(const gstvd_attn_t& a) {
+  return (uint64_t)a.B * (uint64_t)a.nh * (uint64_t)a.Lq * (uint64_t)((a.Lk + 3) & ~3) < (1ull << 33);
+}
+
 template <typename T, int D> static int attn_bwd_launch(const gstvd_attn_t& a, hipStream_t s) {
   constexpr bool BF = sizeof(T) == 2;
+  if constexpr (BF && D == 64) {
+    // one pass per (row, head) when a head's keys fit its 16 waves and there are enough queries to be worth a whole CU
+    // (GSTVD_ATTN_ONEPASS=0: the two-part kernel everywhere, for A/B runs)
+    static const int onepass = [] { const char* e = getenv("GSTVD_ATTN_ONEPASS"); return e ? atoi(e) : 1; }();
+    if (onepass && !a.causal && a.Lk > 64 && a.Lk <= 256 && a.Lq >= 64 && a.Lq <= ONEPASS_MAX_LQ) {
+      constexpr int lds1p = 12 * Img<T, D>::BYTES + 2 * ONEPASS_MAX_LQ * 4;
+      static int rc1 = attn_lds_attr(attn_bwd_onepass_kernel<true>, lds1p) | attn_lds_attr(attn_bwd_onepass_kernel<false>, lds1p);
+      if (rc1) return rc1;
+      dim3 grid((unsigned)a.nh, (unsigned)a.B);
+      if (attn_small_index_space_host(a)) hipLaunchKernelGGL(attn_bwd_onepass_kernel<true>, grid, dim3(1024), lds1p, s, a);
+      else hipLaunchKernelGGL(attn_bwd_onepass_kernel<false>, grid, dim3(1024), lds1p, s, a);
+      GSTVD_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   constexpr int lds1 = (BF ? 3 : 2) * Img<T, D>::BYTES + 64 * 4;
   constexpr int lds2 = (BF ? 4 : 2) * Img<T, D>::BYTES + 128 * 4;
   constexpr int lds = lds1 > lds2 ? lds1 : lds2;

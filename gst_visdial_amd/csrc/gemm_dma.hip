@@ -252,6 +252,11 @@ static int dma_layout(const GemmP& p, int64_t batch, hipStream_t s) {
   // 64x32 tiles -- half the weight bytes per workgroup, twice the workgroups: 8.7-8.8 us against 9.1-9.5 us at M = 400, 18 us
   // against 13 us at M = 592.  Not adopted.)
   // (ring depth 8 / 6 / 5 / 4 measured inside the step in round 3: 1198 / 1202 / 1201 / 1200 rounds/s, i.e. no difference)
+  // GSTVD_GEMM64_NS=3: 48 KB of LDS instead of 128 KB -- a workgroup of the vision / decoder chains then fits on a CU beside a
+  // 96 KB workgroup of the text chain's 128-tile kernels instead of waiting for the CU to drain (round 5 A/B)
+  static const int ns64 = [] { const char* e = getenv("GSTVD_GEMM64_NS"); return e ? atoi(e) : 8; }();
+  if (ns64 == 3) return dma_launch<OT, 64, 64, 2, 2, AKM, BKM, 3>(p, batch, s);
+  if (ns64 == 4) return dma_launch<OT, 64, 64, 2, 2, AKM, BKM, 4>(p, batch, s);
   return dma_launch<OT, 64, 64, 2, 2, AKM, BKM, 8>(p, batch, s);
 }
 

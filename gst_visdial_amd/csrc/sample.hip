@@ -71,6 +71,38 @@ __global__ __launch_bounds__(NT) void sample_topk_kernel(gstvd_sample_t a) {
     }
     zr[j] = v;                                               // (-inf past the end: never selected, never counted below)
   }
+  if (a.ngram > 0 && a.hist && a.ids_tm && a.cur_len >= a.ngram - 1 && a.hist_T >= a.ngram) {
+    // The n-gram filter (utils/decoding_utils.py:38-77) in this launch: one window of the row's history per thread.  A window
+    // bans its last token when it holds no special id and its first n-1 ids are the row's last n-1 generated ids.  The ban
+    // goes into the LDS copy of the row; the register copies (which the top-k passes read) are refreshed from it afterwards.
+    // (The torch-op form -- unfold, compares, a [B, V + 1] scatter -- was ten launches per token inside the captured loop.)
+    const int n = a.ngram;
+    const int64_t* hrow = a.hist + (int64_t)b * a.hist_ld;
+    __syncthreads();                                         // every z[i] of the row is written
+    for (int s0 = tid; s0 + n <= a.hist_T; s0 += NT) {
+      bool hit = true;
+      int64_t last = 0;
+      for (int j = 0; j < n; ++j) {
+        const int64_t t = hrow[s0 + j];
+        for (int q = 0; q < a.n_special; ++q) hit = hit && (t != (int64_t)a.special[q]);
+        if (j < n - 1) hit = hit && (t == a.ids_tm[(int64_t)(a.cur_len - (n - 1) + j) * a.ids_stride + b]);
+        last = t;
+      }
+      if (hit && last >= 0 && last < V) z[last] = -INFINITY;    // (several windows may ban one token: same value, benign)
+    }
+    __syncthreads();
+    m = -INFINITY; c = 0;
+#pragma unroll
+    for (int j = 0; j < SEG; ++j) {
+      const int i = tid + j * NT;
+      if (i < V) {
+        const float v = z[i];
+        zr[j] = v;
+        if (v > m) { m = v; c = 1; }
+        else if (v == m) ++c;
+      }
+    }
+  }
   reduce_maxcount(m, c, smf, smc, tid);                      // (also orders the z[] writes before the reads below)
   const float zmax = m;
   float kth = -INFINITY;
@@ -173,6 +205,8 @@ extern "C" int gstvd_sample_topk(const gstvd_sample_t* a, gstvd_stream_t stream)
   if (a->dtype != GSTVD_F32 && a->dtype != GSTVD_BF16) return GSTVD_E_DTYPE;
   if (a->B <= 0 || a->V <= 0 || a->ld < a->V || a->top_k < 0 || !(a->temperature > 0.f)) return GSTVD_E_SHAPE;
   if (a->V > 31 * 1024) return GSTVD_E_UNSUPPORTED;                         // the row must fit the CU's LDS (and 31 weights per thread)
+  if (a->ngram > 0 && (!a->hist || !a->ids_tm || a->hist_T < 0 || a->cur_len < 0 || a->n_special < 0 || a->n_special > 8 || a->ids_stride < a->B))
+    return a->hist && a->ids_tm ? GSTVD_E_SHAPE : GSTVD_E_NULL;
   hipStream_t s = (hipStream_t)stream;
   return a->dtype == GSTVD_BF16 ? launch<bf16>(*a, s) : launch<float>(*a, s);
 }

@@ -1177,8 +1177,10 @@ class Engine(object):
         captures it together with the decoder stack."""
         from . import decoding
         if Engine._fused_sampling(P, logits.shape[-1]):
-            banned = decoding.ngram_banned_mask(hist, cur[:pos].t(), P["ngram"], logits.shape[-1], logits.device)
-            ops.sample_topk(logits, P["temperature"], P["top_k"], u_row, cur[pos], banned)
+            # the n-gram ban (utils/decoding_utils.py:38-77) runs inside the sampling launch: `hist` and the time-major id buffer
+            # are all it needs (round 4 built a [B, V + 1] mask with ten torch launches per token: +2 ms per questioner decode)
+            ops.sample_topk(logits, P["temperature"], P["top_k"], u_row, cur[pos], None,
+                            ngram=(hist, cur, pos, P["ngram"]) if P["ngram"] > 0 else None)
             return
         last = logits.float() / P["temperature"]
         last = decoding.batch_ngram_blocking(last, hist, cur[:pos].t(), ngram_size=P["ngram"])

@@ -222,12 +222,12 @@ def _splitk_scratch(device):
     return ws
 
 
-GROUP_ORDER = int(os.environ.get("GSTVD_GROUP_ORDER", "2"))       # 0: the library's own chunked order (rounds 1-4); 1 / 2: xcd_block_map
+GROUP_ORDER = int(os.environ.get("GSTVD_GROUP_ORDER", "1"))       # 0: the library's own chunked order (rounds 1-4); 1 / 2: xcd_block_map
 N_XCD = 8
 GROUP_ORDER_MIN_TILES = 4 * N_XCD * 32      # a few rounds of the chip at least: below that the order is moot (tests lower it)
 
 
-def xcd_block_map(shapes, tile, fused_epilogue, mode=2, unit_tiles=40):
+def xcd_block_map(shapes, tile, fused_epilogue, mode=1, unit_tiles=40):
     """Placement of a grouped launch's tiles (gstvd_gemm_grouped*'s block_map_dev): -> list of tile ids, one per workgroup, -1 =
     idle; entries b, b + 8, b + 16, ... are the queue of ONE XCD (workgroups are dealt to the eight XCDs round-robin).
 
@@ -663,10 +663,15 @@ SAMPLE_MAX_TOP_K = 64      # beyond this (or with top-p) the filter runs as torc
 SAMPLE_MAX_VOCAB = 31 * 1024   # a row of scaled logits lives in one CU's LDS (and 31 registers per thread)
 
 
-def sample_topk(logits, temperature, top_k, u, out, banned=None):
+SPECIAL_TOKEN_IDS = (0, 100, 101, 102, 103)      # utils/decoding_utils.py:38 (the default no reference caller overrides)
+
+
+def sample_topk(logits, temperature, top_k, u, out, banned=None, ngram=None):
     """One sampling step (gstvd_sample_topk): out[b] <- inverse-CDF draw from softmax(top_k(logits / temperature, banned -> -inf)).
     logits [B, V] fp32 / bf16 (row stride free); u [B] fp32 in (0, 1); out: int64 view with B elements (any stride, e.g. a
-    column of the id buffer); banned: None or bool / uint8 [B, >= V]."""
+    column of the id buffer); banned: None or bool / uint8 [B, >= V].
+    ngram = (hist [B, T] int64, ids_tm [L, B] int64 time-major, cur_len, n[, special ids]): the n-gram filter of
+    utils/decoding_utils.py:38-77 inside the same launch (the row's last n-1 ids are ids_tm[cur_len-(n-1) : cur_len, b])."""
     lib = L.load()
     Bn, V = logits.shape
     d = L.SampleDesc()
@@ -680,6 +685,17 @@ def sample_topk(logits, temperature, top_k, u, out, banned=None):
         if banned.dtype not in (torch.bool, torch.uint8) or banned.stride(1) != 1 or banned.shape[1] < V:
             raise L.GstvdError("sample_topk: banned must be bool / uint8 [B, >= V] with dense rows")
         d.banned, d.banned_ld = _p(banned), banned.stride(0)
+    if ngram is not None and int(ngram[3]) > 0:
+        hist, ids_tm, cur_len, n = ngram[:4]
+        special = tuple(ngram[4]) if len(ngram) > 4 else SPECIAL_TOKEN_IDS
+        if hist.dtype != torch.int64 or ids_tm.dtype != torch.int64 or hist.stride(1) != 1 or ids_tm.stride(1) != 1 or hist.shape[0] != Bn:
+            raise L.GstvdError("sample_topk: hist [B, T] and ids_tm [L, B] must be int64 with dense rows")
+        if len(special) > 8 or ids_tm.shape[0] < cur_len:
+            raise L.GstvdError("sample_topk: at most 8 special ids; ids_tm must hold cur_len positions")
+        d.hist, d.hist_ld, d.hist_T, d.ngram = _p(hist), hist.stride(0), hist.shape[1], int(n)
+        d.ids_tm, d.ids_stride, d.cur_len, d.n_special = _p(ids_tm), ids_tm.stride(0), int(cur_len), len(special)
+        for i, t in enumerate(special):
+            d.special[i] = int(t)
     L.check("gstvd_sample_topk", lib.gstvd_sample_topk(C.byref(d), _stream()))
 
 

@@ -244,10 +244,18 @@ int gstvd_answer_scores(const void* logits, int64_t ldl, const float* lse, const
  * utils/decoding_utils.py:4-35 for the top-k rule): z = logits / temperature (banned -> -inf); top_k > 0: z below the k-th
  * largest z -> -inf (ties with it stay); out[b * out_stride] = first index whose cumulative softmax probability reaches
  * u[b] * total (inverse CDF -- the draw the oracle substitutes for the reference's torch.multinomial, whose stream is device
- * specific).  logits [B, ld >= V] fp32 or bf16; banned: NULL or uint8 [B, banned_ld >= V]; u [B] in (0, 1). */
+ * specific).  logits [B, ld >= V] fp32 or bf16; banned: NULL or uint8 [B, banned_ld >= V]; u [B] in (0, 1).
+ * ngram > 0 (ABI 5): the n-gram filter itself, utils/decoding_utils.py:38-77 (batch_ngram_blocking + _get_generated_ngrams), runs
+ * in the same launch -- a token is banned when it would complete an n-gram that occurs in the row's history hist[b, 0..hist_T)
+ * (int64 ids, row stride hist_ld; n-grams that contain one of the n_special ids in `special` are ignored) and whose first n-1
+ * tokens are the row's last n-1 generated ids: ids_tm[(cur_len - (n-1) + j) * ids_stride + b], j < n-1, read from the TIME-MAJOR
+ * id buffer [positions, ids_stride >= B].  Nothing is banned while cur_len < n-1 or hist_T < n (the reference's slice
+ * semantics).  It composes with `banned` (either bans). */
 typedef struct {
   const void* logits; int64_t ld; int32_t dtype; int32_t B; int32_t V; int32_t top_k; float temperature;
   const float* u; int64_t* out; int64_t out_stride; const uint8_t* banned; int64_t banned_ld;
+  const int64_t* hist; int64_t hist_ld; int32_t hist_T; int32_t ngram;
+  const int64_t* ids_tm; int64_t ids_stride; int32_t cur_len; int32_t n_special; int32_t special[8];
 } gstvd_sample_t;
 int gstvd_sample_topk(const gstvd_sample_t* a, gstvd_stream_t s);
 
