@@ -252,12 +252,15 @@ static int dma_layout(const GemmP& p, int64_t batch, hipStream_t s) {
   // 64x32 tiles -- half the weight bytes per workgroup, twice the workgroups: 8.7-8.8 us against 9.1-9.5 us at M = 400, 18 us
   // against 13 us at M = 592.  Not adopted.)
   // (ring depth 8 / 6 / 5 / 4 measured inside the step in round 3: 1198 / 1202 / 1201 / 1200 rounds/s, i.e. no difference)
-  // GSTVD_GEMM64_NS=3: 48 KB of LDS instead of 128 KB -- a workgroup of the vision / decoder chains then fits on a CU beside a
-  // 96 KB workgroup of the text chain's 128-tile kernels instead of waiting for the CU to drain (round 5 A/B)
-  static const int ns64 = [] { const char* e = getenv("GSTVD_GEMM64_NS"); return e ? atoi(e) : 8; }();
-  if (ns64 == 3) return dma_launch<OT, 64, 64, 2, 2, AKM, BKM, 3>(p, batch, s);
+  // Round 5: THREE stages (48 KB of LDS) instead of eight (128 KB).  Alone the kernel runs the same (round 3's depth sweep), but a
+  // 128 KB workgroup of the vision / decoder chains could only start on a CU that a text-chain workgroup (96 KB, 128-tile kernels)
+  // had just left -- 8.6-11.9 us alone against 25.8-33.8 us whenever a text kernel was in flight (profiles/r04_overlap_stats.txt);
+  // with 48 KB it fits beside one: whole step 12.40 / 12.45 (8 stages) vs 12.37 / 12.37 (4) vs 12.23 / 12.24 ms (3),
+  // profiles/r05_gemm64_ns_ab.txt.  GSTVD_GEMM64_NS=8 / 4 restore the deeper rings for A/B runs.
+  static const int ns64 = [] { const char* e = getenv("GSTVD_GEMM64_NS"); return e ? atoi(e) : 3; }();
+  if (ns64 == 8) return dma_launch<OT, 64, 64, 2, 2, AKM, BKM, 8>(p, batch, s);
   if (ns64 == 4) return dma_launch<OT, 64, 64, 2, 2, AKM, BKM, 4>(p, batch, s);
-  return dma_launch<OT, 64, 64, 2, 2, AKM, BKM, 8>(p, batch, s);
+  return dma_launch<OT, 64, 64, 2, 2, AKM, BKM, 3>(p, batch, s);
 }
 
 template <typename OT>
@@ -270,9 +273,20 @@ static int dma_out(const GemmP& p, int64_t batch, int akm, int bkm, hipStream_t 
 
 constexpr int SPLITK_MAX_TILES = 1024;      // counters occupy the first 4 KiB of the scratch, partials follow
 
+template <typename OT, bool AKM, bool BKM, int NS>
+static int splitk_launch_ns(const GemmP& p, int S, void* ws, int64_t ws_bytes, hipStream_t s);
+
 template <typename OT, bool AKM, bool BKM>
 static int splitk_launch(const GemmP& p, int S, void* ws, int64_t ws_bytes, hipStream_t s) {
-  constexpr int BM = 64, BN = 64, NS = 8, lds = NS * (BM + BN) * 128;
+  // ring depth of the split-K form: 8 (rounds 2-4) or, GSTVD_GEMM64_SK_NS=4, four stages / 64 KB (A/B)
+  static const int ns = [] { const char* e = getenv("GSTVD_GEMM64_SK_NS"); return e ? atoi(e) : 8; }();
+  if (ns == 4) return splitk_launch_ns<OT, AKM, BKM, 4>(p, S, ws, ws_bytes, s);
+  return splitk_launch_ns<OT, AKM, BKM, 8>(p, S, ws, ws_bytes, s);
+}
+
+template <typename OT, bool AKM, bool BKM, int NS>
+static int splitk_launch_ns(const GemmP& p, int S, void* ws, int64_t ws_bytes, hipStream_t s) {
+  constexpr int BM = 64, BN = 64, lds = NS * (BM + BN) * 128;
   auto k = gemm_dma_splitk_kernel<OT, BM, BN, 2, 2, AKM, BKM, NS>;
   static int attr_rc = ensure_lds(k, lds);
   if (attr_rc) return attr_rc;

@@ -17,7 +17,8 @@ FAM = [("ln_bwd 16 waves (4096 rows)", "ln_bwd_kernelIDF16bLi0ELi3ELi1ELi16"), (
        ("gemm 256-tile NT (full-line)", "gemm_pc256_nt64"), ("gemm 256-tile NN", "gemm_pc256_kernelIDF16bLb0ELb1"),
        ("gemm 64-tile NN", "gemm_dma_kernelIDF16bLi64ELi64ELi2ELi2ELb0ELb1"), ("gemm 64-tile NT", "gemm_dma_kernelIDF16bLi64ELi64ELi2ELi2ELb0ELb0"),
        ("attn_fwd d=64", "attn_fwd_kernelIDF16bLi64"), ("attn_bwd d=64", "attn_bwd_kernelIDF16bLi64"),
-       ("attn_fwd d=128", "attn_fwd_kernelIDF16bLi128"), ("attn_bwd d=128", "attn_bwd_kernelIDF16bLi128")]
+       ("attn_fwd d=128", "attn_fwd_kernelIDF16bLi128"), ("attn_bwd d=128", "attn_bwd_kernelIDF16bLi128"),
+       ("attn_bwd one pass (round 5)", "attn_bwd_onepass")]
 print("step %d of %s: %d kernels, %.3f ms" % (which, os.path.basename(path), len(ev), (max(e for _, e, _, _ in ev) - ev[0][0]) / 1e6))
 print("%-32s %8s %10s %8s %12s" % ("kernel family", "alone", "mean us", "overl.", "mean us"))
 for label, key in FAM:
