@@ -53,7 +53,7 @@ class AttnDesc(C.Structure):
                 ("mask_neg", _f32), ("scale", _f32), ("dropout_p", _f32), ("site", _u32), ("rng", _vp),
                 ("dO", _vp), ("lddo", _i64), ("dQ", _vp), ("dK", _vp), ("dV", _vp),
                 ("lddq", _i64), ("lddk", _i64), ("lddv", _i64), ("delta", _vp), ("kv_group", _i32),
-                ("q_bstride", _i32), ("kv_bstride", _i32)]
+                ("q_bstride", _i32), ("kv_bstride", _i32), ("drop_bits", _vp)]
 
 
 class SampleDesc(C.Structure):

@@ -254,6 +254,10 @@ DEVFN void attn_fwd_body(const gstvd_attn_t& a, char* smem) {
   const DropKey dk = make_drop(a.dropout_p, a.site, a.rng);
   const int Lkp = round4(a.Lk);
   const uint64_t ebase = ((uint64_t)(b * a.nh + h) * a.Lq + (uint64_t)(qv ? q : 0)) * (uint64_t)Lkp + (uint64_t)(4 * g);
+  // keep-bit output (gstvd_attn_t.drop_bits): this wave's 16-query tile is tile `qtile` of [B, nh, ceil(Lq/16), ceil(Lk/16), 4]
+  const int nkt16 = (a.Lk + 15) >> 4;
+  unsigned long long* kbits = (dk.on && a.kv_group <= 1) ? (unsigned long long*)a.drop_bits : nullptr;
+  const int64_t qtile = ((int64_t)(b * a.nh + h) * ((a.Lq + 15) >> 4)) + (blockIdx.x * 4 + wave);
 
   float m_run = -1e30f, l_part = 0.f;
   f32x4 accO[D / 16];
@@ -324,6 +328,12 @@ DEVFN void attn_fwd_body(const gstvd_attn_t& a, char* smem) {
       for (int t = 0; t < TF; ++t) {
         if (FULL || t < nt) {
           const f32x4 fac = drop_factor4e<E32>(dk, ebase + (uint64_t)(c0 + k0 + t * 16));
+          if (D == 64 && sizeof(T) == 2 && kbits != nullptr) {
+            // the keep bits of this 16 x 16 tile for the one-pass backward: word r = ballot of "element (query li, key 4g + r) kept"
+            const unsigned long long w0 = __builtin_amdgcn_ballot_w64(fac[0] != 0.f), w1 = __builtin_amdgcn_ballot_w64(fac[1] != 0.f);
+            const unsigned long long w2 = __builtin_amdgcn_ballot_w64(fac[2] != 0.f), w3 = __builtin_amdgcn_ballot_w64(fac[3] != 0.f);
+            if (lane < 4) kbits[((int64_t)qtile * nkt16 + ((c0 + k0) >> 4) + t) * 4 + lane] = lane == 0 ? w0 : lane == 1 ? w1 : lane == 2 ? w2 : w3;
+          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float p = __expf(val[t][r] - m_new);
@@ -759,7 +769,7 @@ DEVFN void attn_bwd_dkv_body(const gstvd_attn_t& a, const int bx, char* smem) {
 // LDS: Q and dO chunk images (row + transposed-read, 4 x 8 KB), K (32 KB), dS (32 KB), LSE / delta of all queries (8 KB): 104 KB;
 // one workgroup per CU.
 constexpr int ONEPASS_MAX_LQ = 1024;
-template <bool E32>
+template <bool E32, bool BITS>      // BITS: the dropout keep bits come from forward (gstvd_attn_t.drop_bits) instead of the counter hash
 __global__ __launch_bounds__(1024) void attn_bwd_onepass_kernel(gstvd_attn_t a) {
   typedef bf16 T;
   constexpr int D = 64, IB = Img<T, D>::BYTES, TP = 2;
@@ -772,6 +782,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_onepass_kernel(gstvd_attn_t a) 
   char* sDs = smem + 8 * IB;                                  // [256 keys][64 queries of the chunk], transposed-read image
   float* sLse = (float*)(smem + 12 * IB);                     // [ONEPASS_MAX_LQ] LSE of every query (+inf past the end)
   float* sDel = sLse + ONEPASS_MAX_LQ;                        // [ONEPASS_MAX_LQ] delta of every query
+  unsigned long long* sBits = (unsigned long long*)(sDel + ONEPASS_MAX_LQ);   // [4 query tiles][16 key tiles][4] keep bits of the chunk
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = blockIdx.x, b = blockIdx.y;
@@ -830,14 +841,22 @@ __global__ __launch_bounds__(1024) void attn_bwd_onepass_kernel(gstvd_attn_t a) 
     sLse[q] = q < a.Lq ? a.LSE[stat0 + q] : INFINITY;         // +inf => p = 0 for padded query rows
     if (q >= a.Lq) sDel[q] = 0.f;
   }
-  // staging of a 64-query chunk: threads [0, 512) carry one 16-byte piece of Q each, threads [512, 1024) one of dO
+  // staging of a 64-query chunk: threads [0, 512) carry one 16-byte piece of Q each, threads [512, 1024) one of dO; with stored keep
+  // bits (forward's gstvd_attn_t.drop_bits) threads [0, 256) also carry one word of the chunk's 4 x 16 tiles
   u32x4 pv4 = {0u, 0u, 0u, 0u};
+  unsigned long long pbits = ~0ull;
   const bool is_q = tid < 512;
   const int sidx = is_q ? tid : tid - 512, srow = sidx >> 3, scv = sidx & 7;
+  const unsigned long long* kbits = (BITS && dk.on) ? (const unsigned long long*)a.drop_bits : nullptr;
+  const int nqt16 = (a.Lq + 15) >> 4, nkt16 = (a.Lk + 15) >> 4;
   auto prefetch = [&](int c0) {
     pv4 = (u32x4){0u, 0u, 0u, 0u};
     if (c0 + srow < a.Lq) pv4 = is_q ? *(const u32x4*)(Qb + (int64_t)(c0 + srow) * a.ldq + scv * 8)
                                      : *(const u32x4*)(dOb + (int64_t)(c0 + srow) * a.lddo + scv * 8);
+    if (BITS && tid < 256) {
+      const int qt = (c0 >> 4) + (tid >> 6), kt = (tid >> 2) & 15;
+      pbits = (kbits && qt < nqt16 && kt < nkt16) ? kbits[(((int64_t)(b * a.nh + h) * nqt16 + qt) * nkt16 + kt) * 4 + (tid & 3)] : ~0ull;
+    }
   };
   prefetch(0);
   const int nkb = (a.Lk + 31) >> 5;                           // 32-key blocks of the dQ contraction
@@ -851,6 +870,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_onepass_kernel(gstvd_attn_t a) 
       *(u32x4*)(sOr + Img<T, D>::row_off(srow, scv)) = pv4;
       *(u32x4*)(sOt + Img<T, D>::tr_off(srow, scv * 8)) = pv4;
     }
+    if (BITS && tid < 256) sBits[tid] = pbits;
     __syncthreads();
     if (c0 + 64 < a.Lq) prefetch(c0 + 64);
     const uint64_t e2chunk = e2lane + (uint64_t)c0 * half;
@@ -869,7 +889,12 @@ __global__ __launch_bounds__(1024) void attn_bwd_onepass_kernel(gstvd_attn_t a) 
         const f32x4 lse4 = *(const f32x4*)(sLse + c0 + q0 + 4 * g);
         const f32x4 del4 = *(const f32x4*)(sDel + c0 + q0 + 4 * g);
         float f[4] = {1.f, 1.f, 1.f, 1.f};
-        if (dk.on) {      // the two keys of a draw's pair sit in neighbouring lanes: each lane draws for two rows, one quad permute swaps
+        if (BITS) {       // forward's keep bits: word (key & 3) of tile (query tile, this wave's key tile), bits 16 (li >> 2) + 4g + r
+          const unsigned long long w = sBits[(((q0 >> 4) * 16) + wave) * 4 + (li & 3)];
+          const unsigned m4 = (unsigned)(w >> (((li >> 2) << 4) + 4 * g)) & 0xfu;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) f[r] = ((m4 >> r) & 1u) ? dk.scale : 0.f;
+        } else if (!BITS && dk.on) {      // the two keys of a draw's pair sit in neighbouring lanes: each lane draws for two rows, one quad permute swaps
           const int r0 = odd ? 2 : 0;
           const uint32_t mine0 = draw_pair<E32>(dk, e2chunk + (uint64_t)(q0 + r0) * half);
           const uint32_t mine1 = draw_pair<E32>(dk, e2chunk + (uint64_t)(q0 + r0 + 1) * half);
@@ -999,12 +1024,15 @@ template <typename T, int D> static int attn_bwd_launch(const gstvd_attn_t& a, h
     // (GSTVD_ATTN_ONEPASS=0: the two-part kernel everywhere, for A/B runs)
     static const int onepass = [] { const char* e = getenv("GSTVD_ATTN_ONEPASS"); return e ? atoi(e) : 1; }();
     if (onepass && !a.causal && a.Lk > 64 && a.Lk <= 256 && a.Lq >= 64 && a.Lq <= ONEPASS_MAX_LQ) {
-      constexpr int lds1p = 12 * Img<T, D>::BYTES + 2 * ONEPASS_MAX_LQ * 4;
-      static int rc1 = attn_lds_attr(attn_bwd_onepass_kernel<true>, lds1p) | attn_lds_attr(attn_bwd_onepass_kernel<false>, lds1p);
+      constexpr int lds1p = 12 * Img<T, D>::BYTES + 2 * ONEPASS_MAX_LQ * 4 + 256 * 8;
+      static int rc1 = attn_lds_attr(attn_bwd_onepass_kernel<true, false>, lds1p) | attn_lds_attr(attn_bwd_onepass_kernel<false, false>, lds1p) |
+                       attn_lds_attr(attn_bwd_onepass_kernel<true, true>, lds1p);
       if (rc1) return rc1;
       dim3 grid((unsigned)a.nh, (unsigned)a.B);
-      if (attn_small_index_space_host(a)) hipLaunchKernelGGL(attn_bwd_onepass_kernel<true>, grid, dim3(1024), lds1p, s, a);
-      else hipLaunchKernelGGL(attn_bwd_onepass_kernel<false>, grid, dim3(1024), lds1p, s, a);
+      const bool bits = a.drop_bits != nullptr && a.dropout_p > 0.f && a.rng != nullptr;     // forward left the keep bits of its draws
+      if (bits) hipLaunchKernelGGL((attn_bwd_onepass_kernel<true, true>), grid, dim3(1024), lds1p, s, a);
+      else if (attn_small_index_space_host(a)) hipLaunchKernelGGL((attn_bwd_onepass_kernel<true, false>), grid, dim3(1024), lds1p, s, a);
+      else hipLaunchKernelGGL((attn_bwd_onepass_kernel<false, false>), grid, dim3(1024), lds1p, s, a);
       GSTVD_LAUNCH_CHECK();
       return 0;
     }

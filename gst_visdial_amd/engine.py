@@ -727,10 +727,14 @@ class Engine(object):
         Hh = nh * d
         o = self.act(Bn * Lq, Hh)
         lse = self.vec(Bn * nh * Lq)
+        # text self-attention in training: forward leaves the keep bits of its dropout draws (8 KB per head) for the one-pass
+        # backward, which then reads a bit instead of hashing every draw a second time
+        nbits = ops.attn_keep_bits_shape(Bn, nh, Lq, Lk, d, self.adt, causal, p if (self.train and self.rec) else 0.0) if kv_group == 1 else 0
+        bits = self.arena.alloc(nbits, torch.int64) if nbits else None
         a = ops.attn_desc(qa.t[:, qc:qc + Hh], ka.t[:, kc:kc + Hh], va.t[:, vc:vc + Hh], o.t, lse, key_mask, Bn, nh, Lq, Lk, d,
                           causal=causal, mask_neg=neg, drop_p=p if self.train else 0.0,
                           site=self.site(label, p, "attn", (Bn, nh, Lq, (Lk + 3) // 4 * 4), Lk=Lk), rng=self.rng,
-                          kv_group=kv_group, kv_bstride=kv_bstride)
+                          kv_group=kv_group, kv_bstride=kv_bstride, drop_bits=bits)
         ops.attn_fwd(a)
         self.push(lambda: self._attn_bwd(a, q, k, v, o, Bn, nh, Lq, Hh))
         return o

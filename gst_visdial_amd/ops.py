@@ -606,8 +606,16 @@ def locgrad(dh, loc, M, H, dw_loc, accumulate):
                                                _stream()))
 
 
+def attn_keep_bits_shape(B, nh, Lq, Lk, d, dtype, causal, drop_p):
+    """int64 element count of the keep-bit buffer that attn_desc(drop_bits=...) takes, or 0 when the shape's backward does not read
+    one (the one-pass kernel's range: bf16, d = 64, no causal mask, 64 < keys <= 256, 64 <= queries <= 1024, dropout on)."""
+    if not (dtype == torch.bfloat16 and d == 64 and not causal and drop_p > 0 and 64 < Lk <= 256 and 64 <= Lq <= 1024):
+        return 0
+    return B * nh * ((Lq + 15) // 16) * ((Lk + 15) // 16) * 4
+
+
 def attn_desc(Q, K, V, O, LSE, key_mask, B, nh, Lq, Lk, d, *, causal=False, mask_neg=-10000.0, scale=None, drop_p=0.0,
-              site=0, rng=None, ldq=None, ldk=None, ldv=None, ldo=None, kv_group=1, q_bstride=0, kv_bstride=0):
+              site=0, rng=None, ldq=None, ldk=None, ldv=None, ldo=None, kv_group=1, q_bstride=0, kv_bstride=0, drop_bits=None):
     a = L.AttnDesc()
     a.Q, a.K, a.V, a.O, a.LSE, a.key_mask = _p(Q), _p(K), _p(V), _p(O), _p(LSE), _p(key_mask)
     a.ldq = Q.stride(-2) if ldq is None else ldq
@@ -620,6 +628,11 @@ def attn_desc(Q, K, V, O, LSE, key_mask, B, nh, Lq, Lk, d, *, causal=False, mask
     a.dropout_p, a.site = drop_p, site
     a.rng = rng.ptr() if (rng is not None and drop_p > 0) else None
     a.kv_group, a.q_bstride, a.kv_bstride = kv_group, q_bstride, kv_bstride
+    if drop_bits is not None:
+        need = B * nh * ((Lq + 15) // 16) * ((Lk + 15) // 16) * 4
+        if drop_bits.dtype != torch.int64 or drop_bits.numel() < need or not drop_bits.is_contiguous():
+            raise L.GstvdError("attn_desc: drop_bits must be a contiguous int64 tensor of >= %d elements" % need)
+        a.drop_bits = _p(drop_bits)
     return a
 
 

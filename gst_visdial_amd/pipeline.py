@@ -24,7 +24,10 @@ import torch
 import torch.distributed as dist
 
 
+import os as _os
+
 SHARD_ALIGN = 1024        # a rank's shard of a slice is a multiple of this many elements (16-byte pieces in every dtype, whole AdamW blocks)
+PACK_SLICE_MIN = int(_os.environ.get("GSTVD_PACK_SLICE_MIN", str(1 << 15)))   # fp32-read pieces at least this long travel as slice copies
 
 
 class BackwardPipeline(object):
@@ -218,7 +221,7 @@ class BackwardPipeline(object):
         if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
             raise RuntimeError("BackwardPipeline(shard_update): new slice during a hipGraph capture -- run one eager step first")
         world = self.world
-        rank = dist.get_rank(self.group)
+        rank = self.rank_of_plan = dist.get_rank(self.group)
         L = hi - lo
         S = (L // (world * SHARD_ALIGN)) * SHARD_ALIGN
         bulk = world * S
@@ -230,16 +233,30 @@ class BackwardPipeline(object):
         shadow = getattr(flat, "S", None)
         if S and shadow is not None:
             ranges = flat.fp32_read_ranges() if hasattr(flat, "fp32_read_ranges") else [(0, flat.n_live)]
+            # a rank's packed buffer = its LARGE pieces (an embedding table's share of the shard: plain slice copies) followed by its
+            # small ones (biases, LayerNorm: one index gather); `width` = the longest rank's buffer
+            BIG = PACK_SLICE_MIN
             per_rank = []
             for q in range(world):
                 a, b = lo + q * S, lo + (q + 1) * S
-                idx = [torch.arange(max(a, x), min(b, y), dtype=torch.int64) for (x, y) in ranges if max(a, x) < min(b, y)]
-                per_rank.append(torch.cat(idx) if idx else torch.zeros(0, dtype=torch.int64))
-            width = max(int(i.numel()) for i in per_rank)
+                pieces = [(max(a, x), min(b, y)) for (x, y) in ranges if max(a, x) < min(b, y)]
+                big = [pc for pc in pieces if pc[1] - pc[0] >= BIG]
+                small = [pc for pc in pieces if pc[1] - pc[0] < BIG]
+                sidx = torch.cat([torch.arange(x, y, dtype=torch.int64) for x, y in small]) if small else torch.zeros(0, dtype=torch.int64)
+                per_rank.append((big, sidx))
+            width = max(sum(y - x for x, y in big) + int(sidx.numel()) for big, sidx in per_rank)
             if width:
-                mine = per_rank[rank]
-                src = torch.cat([q * width + torch.arange(i.numel(), dtype=torch.int64) for q, i in enumerate(per_rank)])
-                pl["pack"] = dict(width=width, n_mine=int(mine.numel()), mine=mine.to(dev), dst=torch.cat(per_rank).to(dev), src=src.to(dev),
+                copies, dst, src = [], [], []          # (flat lo, flat hi, offset in `all`) of every rank's large pieces; small: index lists
+                for q, (big, sidx) in enumerate(per_rank):
+                    off = q * width
+                    for x, y in big:
+                        copies.append((x, y, off)); off += y - x
+                    dst.append(sidx); src.append(off + torch.arange(sidx.numel(), dtype=torch.int64))
+                mine_big, mine_small = per_rank[rank]
+                n_big = sum(y - x for x, y in mine_big)
+                dst, src = torch.cat(dst), torch.cat(src)
+                pl["pack"] = dict(width=width, mine_big=mine_big, n_big=n_big, mine_small=mine_small.to(dev), n_small=int(mine_small.numel()),
+                                  copies=copies, dst=dst.to(dev) if dst.numel() else None, src=src.to(dev) if src.numel() else None,
                                   buf=torch.zeros(width, dtype=torch.float32, device=dev),
                                   all=torch.empty(world * width, dtype=torch.float32, device=dev))
         self._plans[key] = pl
@@ -287,10 +304,18 @@ class BackwardPipeline(object):
             dist.all_gather_into_tensor(W[lo:lo + bulk], W[a:b], group=self.group)
             pk = pl["pack"]
             if pk is not None:
-                if pk["n_mine"]:
-                    pk["buf"][:pk["n_mine"]].copy_(flat.P.index_select(0, pk["mine"]))
+                off = 0
+                for x, y in pk["mine_big"]:
+                    pk["buf"][off:off + y - x].copy_(flat.P[x:y]); off += y - x
+                if pk["n_small"]:
+                    pk["buf"][off:off + pk["n_small"]].copy_(flat.P.index_select(0, pk["mine_small"]))
                 dist.all_gather_into_tensor(pk["all"], pk["buf"], group=self.group)
-                flat.P.index_copy_(0, pk["dst"], pk["all"].index_select(0, pk["src"]))
+                mine_lo, mine_hi = self.rank_of_plan * pk["width"], (self.rank_of_plan + 1) * pk["width"]
+                for x, y, o in pk["copies"]:
+                    if not (mine_lo <= o < mine_hi):          # (this rank's own pieces are already in place)
+                        flat.P[x:y].copy_(pk["all"][o:o + y - x])
+                if pk["dst"] is not None:
+                    flat.P.index_copy_(0, pk["dst"], pk["all"].index_select(0, pk["src"]))
 
     def sync_master(self):
         """After sharded steps the fp32 master weights and the moments of a slice's bulk are current only on their owner.

@@ -220,6 +220,12 @@ typedef struct {
                                         re-encodes the identical context 100 times). */
   int32_t q_bstride, kv_bstride;     /* forward only: rows between consecutive batch elements of Q/O resp. K/V (0 = Lq / Lk).
                                         Lets one decode step (Lq = 1) read a [B, Umax, H] K/V cache of which Lk rows are filled. */
+  uint64_t* drop_bits;               /* (ABI 5) NULL, or the dropout keep bits of the probabilities: uint64
+                                        [B, nh, ceil(Lq/16), ceil(Lk/16), 4] -- word r of tile (qt, kt): bit 16 g + i = "keep" of
+                                        (query 16 qt + i, key 16 kt + 4 g + r).  Forward WRITES them when the pointer is set and
+                                        dropout is on (the same draws it applies: nn.Dropout's mask, vilbert_dialog.py:398-401);
+                                        the one-pass backward READS them instead of hashing every draw again (40 % of its vector
+                                        instructions); the other backward kernels ignore them.  bf16, d = 64 only. */
 } gstvd_attn_t;
 int gstvd_attn_fwd(const gstvd_attn_t* a, gstvd_stream_t s);
 int gstvd_attn_bwd(const gstvd_attn_t* a, gstvd_stream_t s);  /* dQ (+delta) then dK,dV */

@@ -156,10 +156,12 @@ def _spawn(world, args):
     return res
 
 
-@pytest.mark.parametrize("world,compress,shadow", [(2, None, True), (2, "bf16", True), (8, "bf16", True), (2, None, False)],
-                         ids=["w2_fp32_payload", "w2_bf16_payload", "w8_bf16_payload", "w2_fp32_precision_no_shadow"])
-def test_sharded_update_matches_allreduce_path(world, compress, shadow):
+@pytest.mark.parametrize("world,compress,shadow,slice_min", [(2, None, True, None), (2, "bf16", True, 2048), (8, "bf16", True, None), (2, None, False, None)],
+                         ids=["w2_fp32_payload", "w2_bf16_payload_slice_copies", "w8_bf16_payload", "w2_fp32_precision_no_shadow"])
+def test_sharded_update_matches_allreduce_path(world, compress, shadow, slice_min, monkeypatch):
     import numpy as np
+    if slice_min is not None:        # (the workers are spawned: they read the threshold from the environment) the large fp32-read
+        monkeypatch.setenv("GSTVD_PACK_SLICE_MIN", str(slice_min))      # range of the stub then travels as slice copies, the small ones by index
     n, steps = 100000, 3
     graded = [30000, 25000, 12000, 6000]
     marks = [90000, 69000, 52000, 44000, 30000, 21000, 12500, 6000, 500, 0]

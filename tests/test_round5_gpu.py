@@ -287,3 +287,49 @@ def test_sampling_kernel_ngram_ban_equals_the_reference_filter(n, dtype):
             assert not want_mask[torch.arange(Bn), out_k.cpu()].any()     # no banned token is ever drawn
         if pos >= n - 1 and n > 1:
             assert want_mask.any()                                        # (the cases really ban something)
+
+
+# ---- dropout keep bits from forward to the one-pass backward --------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(2, 3, 256, 256), (1, 2, 100, 200), (2, 2, 64, 65), (1, 1, 330, 256)])
+def test_attention_keep_bits_equal_the_hashed_mask_and_the_backward_that_reads_them(shape):
+    """gstvd_attn_t.drop_bits: forward writes the keep bit of every probability it drops / keeps (16 x 16 tiles, four ballots each);
+    the one-pass backward reads them instead of hashing each draw again.  The bits ARE the counter-hash mask (checked against the
+    library's mask probe), so the backward's outputs are bit-identical with and without them; ragged query / key counts included."""
+    from gst_visdial_amd import ops
+    Bn, nh, Lq, Lk = shape
+    d, p = 64, 0.1
+    H = nh * d
+    g = torch.Generator().manual_seed(5)
+    qkv = (torch.randn(Bn * max(Lq, Lk), 3 * H, generator=g) * 0.5).to(DEV).bfloat16()
+    Q, K, V = qkv[:Bn * Lq, :H], qkv[:Bn * Lk, H:2 * H], qkv[:Bn * Lk, 2 * H:]
+    km = torch.ones(Bn, Lk, device=DEV)
+    km[0, Lk - Lk // 4:] = 0
+    rng = ops.Rng(DEV, seed=9)
+    n = ops.attn_keep_bits_shape(Bn, nh, Lq, Lk, d, torch.bfloat16, False, p)
+    assert n == Bn * nh * ((Lq + 15) // 16) * ((Lk + 15) // 16) * 4
+    bits = torch.zeros(n, dtype=torch.int64, device=DEV)
+    outs = []
+    for use_bits in (True, False):
+        O = torch.empty(Bn * Lq, H, device=DEV, dtype=torch.bfloat16)
+        lse = torch.empty(Bn, nh, Lq, device=DEV)
+        a = ops.attn_desc(Q, K, V, O, lse, km, Bn, nh, Lq, Lk, d, mask_neg=-10000.0, drop_p=p, site=33, rng=rng,
+                          drop_bits=bits if use_bits else None)
+        ops.attn_fwd(a)
+        dO = (torch.randn(Bn * Lq, H, generator=torch.Generator().manual_seed(6)) * 0.3).to(DEV).bfloat16()
+        dQ, dK, dV = torch.full_like(Q, float("nan")), torch.full_like(K, float("nan")), torch.full_like(V, float("nan"))
+        delta = torch.empty(Bn, nh, Lq, device=DEV)
+        ops.attn_bwd(a, dO, dQ, dK, dV, delta)
+        torch.cuda.synchronize()
+        outs.append((O.clone(), dQ.clone(), dK.clone(), dV.clone()))
+    for x, y in zip(*outs):
+        assert torch.isfinite(x.float()).all() and torch.equal(x, y)
+    # the bits against the mask probe: element (b, h, q, k) <-> word (k & 3) of tile (q >> 4, k >> 4), bit 16 * ((k & 15) >> 2) + (q & 15)
+    Lkp = (Lk + 3) // 4 * 4
+    mask = (ops.dropout_mask(Bn * nh * Lq * Lkp, p, 33, rng, DEV).view(Bn, nh, Lq, Lkp)[..., :Lk] != 0).cpu()
+    w = bits.view(Bn, nh, (Lq + 15) // 16, (Lk + 15) // 16, 4).cpu()
+    qi = torch.arange(Lq)[:, None].expand(Lq, Lk)
+    ki = torch.arange(Lk)[None, :].expand(Lq, Lk)
+    word = w[:, :, qi >> 4, ki >> 4, ki & 3]                                  # [Bn, nh, Lq, Lk]
+    got = ((word >> (16 * ((ki & 15) >> 2) + (qi & 15))) & 1) != 0
+    assert torch.equal(got, mask)
+    assert 0.85 < mask.float().mean().item() < 0.95
