@@ -256,8 +256,8 @@ DEVFN void attn_fwd_body(const gstvd_attn_t& a, char* smem) {
   const uint64_t ebase = ((uint64_t)(b * a.nh + h) * a.Lq + (uint64_t)(qv ? q : 0)) * (uint64_t)Lkp + (uint64_t)(4 * g);
   // keep-bit output (gstvd_attn_t.drop_bits): this wave's 16-query tile is tile `qtile` of [B, nh, ceil(Lq/16), ceil(Lk/16), 4]
   const int nkt16 = (a.Lk + 15) >> 4;
-  unsigned long long* kbits = (dk.on && a.kv_group <= 1) ? (unsigned long long*)a.drop_bits : nullptr;
-  const int64_t qtile = ((int64_t)(b * a.nh + h) * ((a.Lq + 15) >> 4)) + (blockIdx.x * 4 + wave);
+  unsigned long long* kbits = (dk.on && a.kv_group <= 1 && (int)(blockIdx.x * 4 + wave) < ((a.Lq + 15) >> 4)) ? (unsigned long long*)a.drop_bits : nullptr;
+  const int64_t qtile = ((int64_t)(b * a.nh + h) * ((a.Lq + 15) >> 4)) + (blockIdx.x * 4 + wave);     // (a wave past the last query tile writes nothing)
 
   float m_run = -1e30f, l_part = 0.f;
   f32x4 accO[D / 16];

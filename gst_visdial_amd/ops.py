@@ -606,10 +606,13 @@ def locgrad(dh, loc, M, H, dw_loc, accumulate):
                                                _stream()))
 
 
+KEEP_BITS = int(os.environ.get("GSTVD_ATTN_KEEP_BITS", "1"))     # 0: the backward hashes its dropout draws again (A/B)
+
+
 def attn_keep_bits_shape(B, nh, Lq, Lk, d, dtype, causal, drop_p):
     """int64 element count of the keep-bit buffer that attn_desc(drop_bits=...) takes, or 0 when the shape's backward does not read
     one (the one-pass kernel's range: bf16, d = 64, no causal mask, 64 < keys <= 256, 64 <= queries <= 1024, dropout on)."""
-    if not (dtype == torch.bfloat16 and d == 64 and not causal and drop_p > 0 and 64 < Lk <= 256 and 64 <= Lq <= 1024):
+    if not (KEEP_BITS and dtype == torch.bfloat16 and d == 64 and not causal and drop_p > 0 and 64 < Lk <= 256 and 64 <= Lq <= 1024):
         return 0
     return B * nh * ((Lq + 15) // 16) * ((Lk + 15) // 16) * 4
 
