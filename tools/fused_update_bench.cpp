@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <algorithm>
 #include "../include/gstvd_hip.h"
 
 static void* dmalloc(size_t n, int byte = 0) { void* p; if (hipMalloc(&p, n) != hipSuccess) { fprintf(stderr, "hipMalloc %zu failed\n", n); exit(1); } (void)hipMemset(p, byte, n); return p; }
@@ -31,6 +32,7 @@ static void fill_f32(float* p, size_t n, float scale, unsigned seed, float bias 
 
 int main(int argc, char** argv) {
   const int nb = argc > 1 ? atoi(argv[1]) : 24, ns = argc > 2 ? atoi(argv[2]) : 12;
+  const int order = argc > 3 ? atoi(argv[3]) : 0;       // 1: per-XCD queues of whole problems, long K first (round 5's block_map_dev)
   const int np = nb + ns;
   std::vector<int64_t> M(np), N(np), K(np), off(np + 1);
   int64_t tot = 1024;                                             // flat offset of the first weight (something sits in front of it)
@@ -91,11 +93,34 @@ int main(int argc, char** argv) {
   int32_t* toff_d = (int32_t*)dmalloc(np * 4);
   (void)hipMemcpy(tab_d, tab.data(), np * sizeof(gstvd_gemm_t), hipMemcpyHostToDevice); (void)hipMemcpy(tabf_d, tabf.data(), np * sizeof(gstvd_gemm_t), hipMemcpyHostToDevice);
   (void)hipMemcpy(toff_d, toff.data(), np * 4, hipMemcpyHostToDevice);
+  // round 5: the placement ops.xcd_block_map builds, restated for this table -- whole problems dealt to the least-loaded XCD queue,
+  // long-K problems first; workgroup b runs tile bmap[b] (entries b, b + 8, ... = one XCD's queue), -1 = idle
+  int32_t* bmap_d = nullptr; int64_t nblocks = 0;
+  if (order) {
+    std::vector<int> idx(np);
+    for (int i = 0; i < np; ++i) idx[i] = i;
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return K[a] > K[b]; });
+    std::vector<std::vector<int32_t>> q(8); double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i : idx) {
+      int x = 0; for (int j = 1; j < 8; ++j) if (load[j] < load[x]) x = j;
+      const int32_t nt = (int32_t)(((M[i] + 255) / 256) * ((N[i] + 255) / 256));
+      for (int32_t t = 0; t < nt; ++t) q[x].push_back(toff[i] + t);
+      load[x] += nt * (35.0 + 0.76 * ((K[i] + 31) / 32));
+    }
+    size_t depth = 0; for (auto& v : q) depth = v.size() > depth ? v.size() : depth;
+    std::vector<int32_t> bm(depth * 8, -1);
+    for (int x = 0; x < 8; ++x) for (size_t j = 0; j < q[x].size(); ++j) bm[j * 8 + x] = q[x][j];
+    nblocks = (int64_t)bm.size();
+    bmap_d = (int32_t*)dmalloc(bm.size() * 4); (void)hipMemcpy(bmap_d, bm.data(), bm.size() * 4, hipMemcpyHostToDevice);
+    printf("block map: %lld workgroups for %d tiles, queue depths", (long long)nblocks, tiles);
+    for (auto& v : q) printf(" %zu", v.size());
+    printf("\n");
+  }
   hipStream_t s0; (void)hipStreamCreate(&s0);
   hipEvent_t e0, e1, em; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventCreate(&em);
   const float b1 = 0.9f, b2 = 0.999f, eps = 1e-6f, gs = 1.f;
   auto plain = [&](int c) {
-    int rc = gstvd_gemm_grouped(tab_d, toff_d, np, tiles, GSTVD_BF16, GSTVD_F32, 1, 1, nullptr, 0, s0);
+    int rc = gstvd_gemm_grouped(tab_d, toff_d, np, tiles, GSTVD_BF16, GSTVD_F32, 1, 1, bmap_d, nblocks, s0);
     (void)hipEventRecord(em, s0);
     rc |= gstvd_adamw(P[c], G, Mo[c], V[c], S[c], n, seg_d, hp_d, nseg, b1, b2, eps, step, gs, 0, s0);
     return rc;
@@ -104,7 +129,7 @@ int main(int argc, char** argv) {
     gstvd_adamw_fuse_t f; memset(&f, 0, sizeof(f));
     f.grad_base = G; f.param = P[c]; f.m = Mo[c]; f.v = V[c]; f.shadow_bf16 = S[c]; f.step = step;
     f.beta1 = b1; f.beta2 = b2; f.eps = eps; f.grad_scale = gs; f.write_grad = 0;
-    int rc = gstvd_gemm_grouped_adamw(tabf_d, toff_d, np, tiles, &f, nullptr, 0, s0);
+    int rc = gstvd_gemm_grouped_adamw(tabf_d, toff_d, np, tiles, &f, bmap_d, nblocks, s0);
     (void)hipEventRecord(em, s0);
     rc |= gstvd_adamw_blocks(P[c], G, Mo[c], V[c], S[c], n, seg_d, hp_d, nseg, b1, b2, eps, step, gs, 0, blocks_d, (int64_t)blocks.size(), skip_d, s0);
     return rc;
