@@ -207,7 +207,13 @@ def test_model_step_with_the_update_in_the_weight_gradient_launch_is_bit_identic
     for k in ("param", "m", "v", "shadow"):
         a, b = ref[k], got[k]
         assert torch.equal(a[det], b[det]), (k, (a.float() - b.float())[det].abs().max().item(), int((a != b)[det].sum()))
-        assert (a.float() - b.float()).abs().max().item() < 1e-6, k
+        # the atomically accumulated tables (embedding gradients: the order of the atomic adds is the hardware's) differ in the last
+        # fp32 bits from run to run; that can flip the rounding of a bf16 shadow weight -- one ulp (2^-7 relative) there, 1e-6 elsewhere
+        d = (a.float() - b.float()).abs()
+        if k == "shadow" and a.dtype == torch.bfloat16:
+            assert bool((d <= a.float().abs() * 2.0 ** -7 + 1e-6).all()), k
+        else:
+            assert d.max().item() < 1e-6, k
     assert not any("grouped_adamw" in n for n in ref["names"]) and any("grouped_adamw" in n for n in got["names"]), got["names"][:20]
     assert (chunk > 1 << 30) == (got["slices"] == 1)
     kept = _run_model(True, chunk, True, 1, False)
