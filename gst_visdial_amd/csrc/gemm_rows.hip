@@ -32,13 +32,15 @@ struct RowPro {
 // 14 us of it prologue arithmetic on one CU) against 17.7 / 21 us for the two separate kernels.  16 rows per workgroup (two per
 // wave) make it ~2 us; 128-column tiles keep the B operand's L2 -> LDS traffic at 192 KB per workgroup and the grid at 150 / 450 /
 // 600 workgroups for N = 768 / 2304 / 3072 (two fit a CU: 24 KB A image + 48 KB ring).
-constexpr int ROWS_BM = 16, ROWS_BN = 128, ROWS_NT = 512, ROWS_NS = 3, ROWS_KT_MAX = 12;
+constexpr int ROWS_BM = 16, ROWS_BN = 128, ROWS_NT = 512, ROWS_NS = 3;
 constexpr int ROWS_A_TILE = ROWS_BM * 128, ROWS_B_TILE = ROWS_BN * 128;
 constexpr int ROWS_NPB = ROWS_B_TILE / (ROWS_NT * 16);                                          // LDS-DMA pieces per thread and stage
-// A image + B ring = 72 KB: two workgroups per CU (N = 3072: 600 workgroups = 1.2 rounds instead of 2.3).  The backward's 12 KB of
+// A image + B ring = 72 KB (H <= 768, three 256-column vectors per row: NV = 3) or 80 KB (H <= 1024, NV = 4: the vision stream's
+// width, round 5): two workgroups per CU (N = 3072: 600 workgroups = 1.2 rounds instead of 2.3).  The backward's 12 / 16 KB of
 // column-partial scratch overlays the ring's last slot, which the prologue leaves unfilled.
-constexpr int ROWS_LDS = ROWS_KT_MAX * ROWS_A_TILE + ROWS_NS * ROWS_B_TILE;
-static_assert(4 * 768 * 4 <= ROWS_B_TILE, "partial scratch must fit the free ring slot");
+constexpr int rows_kt_max(int NV) { return NV * 4; }
+constexpr int rows_lds(int NV) { return rows_kt_max(NV) * ROWS_A_TILE + ROWS_NS * ROWS_B_TILE; }
+static_assert(4 * 1024 * 4 <= ROWS_B_TILE, "partial scratch must fit the free ring slot");
 
 // B operand: ROWS_NPB 16-byte units per thread and stage (128 columns x 64 k = 16 KB), lane-linear LDS image with the read
 // swizzle applied to the source address (same images as gemm_dma.hip: rm_off / km_off_bf16)
@@ -81,12 +83,13 @@ struct DmaB {
 DEVFN f32x4 unpack4(const bf16x4& v) { return (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; }
 DEVFN bf16x4 pack4(const f32x4& v) { return (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]}; }
 
-// PRO = 1: LayerNorm forward prologue; PRO = 2: LayerNorm backward prologue.  H = K <= 768, H % 256 == 0 or H == 768 handled by
-// the `c < H` guards exactly like layernorm.hip (NV = 3).
-template <typename OT, bool BKM, int PRO>
-__global__ __launch_bounds__(ROWS_NT, 2) void gemm_rows_kernel(GemmP p, RowPro r, int ntn) {
+// PRO = 1: LayerNorm forward prologue; PRO = 2: LayerNorm backward prologue.  H = K <= 256 NV, narrower rows handled by the
+// `c < H` guards exactly like layernorm.hip (NV = 3 for H <= 768, NV = 4 for H <= 1024: ln_fwd_nv's / ln_bwd's choice).
+template <typename OT, bool BKM, int PRO, int NV>
+__global__ __launch_bounds__(ROWS_NT, 4) void gemm_rows_kernel(GemmP p, RowPro r, int ntn) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NV = 3, RPW = ROWS_BM / 8;              // rows per wave in the prologue (2)
+  constexpr int RPW = ROWS_BM / 8;                      // rows per wave in the prologue (2)
+  constexpr int HS = NV * 256;                          // stride of a per-wave column-partial slab
   const gstvd_ln_t& f = r.f;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(ROWS_NT, 2) void gemm_rows_kernel(GemmP p, RowPro r
   const int mt = blockIdx.x / ntn, nt = blockIdx.x % ntn;
   const int64_t m0 = (int64_t)mt * ROWS_BM, n0 = (int64_t)nt * ROWS_BN;
   char* A_img = smem;
-  char* ring = smem + ROWS_KT_MAX * ROWS_A_TILE;
+  char* ring = smem + rows_kt_max(NV) * ROWS_A_TILE;
   float* scratch = (float*)(ring + (ROWS_NS - 1) * ROWS_B_TILE);       // the slot the prologue's DMAs do not touch
 
   // ---- B ring: the first stages fly while the prologue runs
@@ -131,11 +134,14 @@ __global__ __launch_bounds__(ROWS_NT, 2) void gemm_rows_kernel(GemmP p, RowPro r
   for (int i = 0; i < NV; ++i) {
     const int c = lane * 4 + i * 256;
     gam[i] = bet[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (c < H) { gam[i] = *(const f32x4*)(f.gamma + c); if (PRO == 1) bet[i] = *(const f32x4*)(f.beta + c); }
+    if (c < H && (PRO == 1 || NV <= 3)) gam[i] = *(const f32x4*)(f.gamma + c);
+    if (c < H && PRO == 1) bet[i] = *(const f32x4*)(f.beta + c);
   }
-  f32x4 ag[NV], ab[NV], ax[NV];
+  // column partials: a column tile emits ONE of the three vectors (tile 0: sum dy * xhat, 1: sum dy, 2: sum dx), so one accumulator
+  // (same sums in the same order as three would give; 8 NV registers less -- what lets NV = 4 stay inside 128)
+  f32x4 mv[NV];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) ag[i] = ab[i] = ax[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < NV; ++i) mv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
   for (int j = 0; j < RPW; ++j) {
@@ -188,7 +194,7 @@ __global__ __launch_bounds__(ROWS_NT, 2) void gemm_rows_kernel(GemmP p, RowPro r
         if (rv && c < H) {
           xh[i] = (h[i] - mean_[j]) * rstd_[j];
           dyv[i] = unpack4(pd[j][i]);
-          gy[i] = dyv[i] * gam[i];
+          gy[i] = dyv[i] * (NV > 3 ? *(const f32x4*)(f.gamma + c) : gam[i]);     // (NV = 4: 16 registers the prologue does not have)
           s1 += gy[i][0] + gy[i][1] + gy[i][2] + gy[i][3];
           const f32x4 t = gy[i] * xh[i];
           s2 += t[0] + t[1] + t[2] + t[3];
@@ -201,10 +207,8 @@ __global__ __launch_bounds__(ROWS_NT, 2) void gemm_rows_kernel(GemmP p, RowPro r
         f32x4 dx = {0.f, 0.f, 0.f, 0.f};
         if (rv && c < H) {
           const f32x4 dh = (gy[i] - c1 - xh[i] * c2) * rstd_[j];
-          ag[i] += dyv[i] * xh[i];
-          ab[i] += dyv[i];
           dx = dh * drop_factor4(dpre, (uint64_t)(row * f.H + c));
-          ax[i] += dx;
+          mv[i] += nt == 0 ? dyv[i] * xh[i] : (nt == 1 ? dyv[i] : dx);
           if (nt == 3 % ntn && r.dres) *(bf16x4*)((bf16*)r.dres + row * r.lddres + c) = pack4(dh);
           if (nt == 4 % ntn && r.dx && (r.dx != r.dres || dpre.on)) *(bf16x4*)((bf16*)r.dx + row * r.lddx + c) = pack4(dx);
         }
@@ -225,10 +229,7 @@ __global__ __launch_bounds__(ROWS_NT, 2) void gemm_rows_kernel(GemmP p, RowPro r
     // column partials of this 64-row block: column tile 0 -> sum dy * xhat (dgamma), 1 -> sum dy (dbeta), 2 -> sum dx (dbias)
     // eight per-wave vectors through four 3 KB slabs, in a fixed order (no LDS atomics: run-to-run bit identity): waves 4-7
     // park theirs, waves 0-3 add them to their own and park the sums, then all threads add the four slabs
-    f32x4 mv[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) mv[i] = nt == 0 ? ag[i] : (nt == 1 ? ab[i] : ax[i]);
-    float* mine = scratch + (wave & 3) * 768;
+    float* mine = scratch + (wave & 3) * HS;
     if (wave >= 4) {
 #pragma unroll
       for (int i = 0; i < NV; ++i) { const int c = lane * 4 + i * 256; if (c < H) *(f32x4*)(mine + c) = mv[i]; }
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(ROWS_NT, 2) void gemm_rows_kernel(GemmP p, RowPro r
     for (int c = tid * 4; c < H; c += ROWS_NT * 4) {
       f32x4 a = *(const f32x4*)(scratch + c);
 #pragma unroll
-      for (int w = 1; w < 4; ++w) a += *(const f32x4*)(scratch + w * 768 + c);
+      for (int w = 1; w < 4; ++w) a += *(const f32x4*)(scratch + w * HS + c);
       *(f32x4*)(out + c) = a;
     }
   }
@@ -283,15 +284,19 @@ __global__ __launch_bounds__(ROWS_NT, 2) void gemm_rows_kernel(GemmP p, RowPro r
   gemm_epilogue_tile<bf16, OT>(p, dk, acc, 0, m0 + li, n0 + wave * 16 + 4 * g);
 }
 
-template <typename OT, bool BKM, int PRO>
-static int rows_launch(const GemmP& p, const RowPro& r, hipStream_t s) {
-  auto k = gemm_rows_kernel<OT, BKM, PRO>;
-  static int attr_rc = ensure_lds(k, ROWS_LDS);
+template <typename OT, bool BKM, int PRO, int NV>
+static int rows_launch_nv(const GemmP& p, const RowPro& r, hipStream_t s) {
+  auto k = gemm_rows_kernel<OT, BKM, PRO, NV>;
+  static int attr_rc = ensure_lds(k, rows_lds(NV));
   if (attr_rc) return attr_rc;
   const int ntm = (int)((p.M + ROWS_BM - 1) / ROWS_BM), ntn = (int)((p.N + ROWS_BN - 1) / ROWS_BN);
-  GSTVD_LAUNCH(k, dim3((unsigned)(ntm * ntn)), dim3(ROWS_NT), ROWS_LDS, s, p, r, ntn);
+  GSTVD_LAUNCH(k, dim3((unsigned)(ntm * ntn)), dim3(ROWS_NT), rows_lds(NV), s, p, r, ntn);
   GSTVD_LAUNCH_CHECK();
   return 0;
+}
+template <typename OT, bool BKM, int PRO>
+static int rows_launch(const GemmP& p, const RowPro& r, hipStream_t s) {
+  return r.f.H <= 768 ? rows_launch_nv<OT, BKM, PRO, 3>(p, r, s) : rows_launch_nv<OT, BKM, PRO, 4>(p, r, s);
 }
 
 static int rows_check(const gstvd_gemm_t* g, const gstvd_ln_t& f, GemmP& p) {
@@ -299,7 +304,7 @@ static int rows_check(const gstvd_gemm_t* g, const gstvd_ln_t& f, GemmP& p) {
   if (g->dtype_in != GSTVD_BF16 || f.dtype != GSTVD_BF16 || f.mode != GSTVD_LN_RESID) return GSTVD_E_UNSUPPORTED;
   if (g->dtype_out != GSTVD_BF16 && g->dtype_out != GSTVD_F32) return GSTVD_E_DTYPE;
   if (g->batch != 1 || g->a_kmajor) return GSTVD_E_UNSUPPORTED;
-  if (f.H != g->K || f.M != g->M || f.H % 64 || f.H > 64 * ROWS_KT_MAX || f.M > 1024 || f.p_post > 0.f) return GSTVD_E_UNSUPPORTED;
+  if (f.H != g->K || f.M != g->M || f.H % 64 || f.H > 64 * rows_kt_max(4) || f.M > 1024 || f.p_post > 0.f) return GSTVD_E_UNSUPPORTED;
   if (g->N < 5 * ROWS_BN || (g->N % 8)) return GSTVD_E_UNSUPPORTED;        // the side outputs are spread over five column tiles
   if (!f.x || !f.gamma || !f.mean || !f.rstd) return GSTVD_E_NULL;
   if ((f.ldx % 4) || (f.res && (f.ldres % 4)) || (g->ldb % 8) || (g->ldc % 4)) return GSTVD_E_ALIGN;

@@ -484,7 +484,19 @@ class Engine(object):
             # the two full-chip kernels do not share the chip profitably; profiles/r03_chunk_sweep.txt.  Not kept.)
             with torch.cuda.stream(self.aux):
                 fused = self.wgrads.flush(fuse=self.pipe.fuse_handle())
-            self.colsums.flush()
+            if os.environ.get("GSTVD_COLSUM_SIDE", "0") == "1":
+                # (A/B, round 5: the same reductions from the vision stream -- does the graph executor then start the grouped
+                # launch without waiting for them?)
+                ev = torch.cuda.Event()
+                ev.record(self.main)
+                self.side.wait_event(ev)
+                with torch.cuda.stream(self.side):
+                    self.colsums.flush()
+                ev = torch.cuda.Event()
+                ev.record(self.side)
+                self.main.wait_event(ev)
+            else:
+                self.colsums.flush()
             ev = torch.cuda.Event()
             ev.record(self.main)
             self.aux.wait_event(ev)
@@ -679,17 +691,29 @@ class Engine(object):
         return y
 
     def _embed_bwd(self, kw, prefix, y, M, H):
-        tabs = []
+        tabs, fresh = [], []
         for n in (".word", ".pos", ".tt", ".tte"):
             gv, acc = self.grad_slot(prefix + n)
             if not acc:
-                gv.zero_()
+                fresh.append(n)
             elif self.wgrads.pending_into(gv):
                 # the LM head tied to this table (FlatParams aliases lm.w onto it when train_gen.py:293 was not applied) has its
                 # weight-gradient GEMM queued: run the queue now, in order, WITHOUT the fused update -- the scatter-add below is a
                 # second contribution to the same slot, and a GEMM launched later would overwrite it
                 self.wgrads.flush()
             tabs.append(gv)
+        if len(fresh) == 4:
+            # the four tables are laid out back to back (FlatParams.emb; alignment gaps and the word table's row padding belong to
+            # no parameter): one fill instead of four dependent ones on the backward chain
+            lo = self.flat.slots[prefix + ".word"][0]
+            hi = self.flat.slots[prefix + ".tte"][0] + tabs[3].numel()
+            if not (0 <= hi - lo <= sum(t.numel() for t in tabs) + self.flat.Vp * H + 4 * 64):
+                raise GstvdError("internal: embedding tables are not contiguous in the flat buffer")
+            self.flat.G[lo:hi].zero_()
+        else:
+            for n, gv in zip((".word", ".pos", ".tt", ".tte"), tabs):
+                if n in fresh:
+                    gv.zero_()
         nblk = ops.ln_bwd_blocks(M)
         partial = self.arena.alloc(nblk * 4 * H, torch.float32)
         ops.ln_bwd(kw, y.g, partial, dword=tabs[0], dpos=tabs[1], dtt=tabs[2], dtt_ext=tabs[3])
@@ -749,16 +773,22 @@ class Engine(object):
         ops.attn_bwd(a, o.g, gs[0], gs[1], gs[2], delta)
 
     # ------------------------------------------------------------------------------------------ blocks
-    def self_block(self, p, x, Bn, L, H, nh, key_mask, pa, ph, causal=False):
-        """QKV -> attention -> output dense -> dropout -> LN(+x)   (vilbert_dialog.py:380-431)"""
+    def self_block(self, p, x, Bn, L, H, nh, key_mask, pa, ph, causal=False, inter=0):
+        """QKV -> attention -> output dense -> dropout -> LN(+x)   (vilbert_dialog.py:380-431).  With `inter` the FFN's first
+        Linear (+ GELU) is issued with the LayerNorm (ln_lin: one launch at the vision stream's row counts, the two kernels at
+        the text stream's) and (x1, a) is returned for ffn_block(..., a=a)."""
         qkv = self.lin(x, p + ".qkv.w", p + ".qkv.b", 3 * H, H)
         ctx = self.attn((qkv, 0), (qkv, H), (qkv, 2 * H), Bn, nh, L, L, H // nh, key_mask, causal, -10000.0, pa, label=p + ".attn")
         ao = self.lin(ctx, p + ".ao.w", p + ".ao.b", H, H)
+        if inter:
+            return self.ln_lin(ao, x, p + ".ln1.w", p + ".ln1.b", H, ph, p + ".ao.b", 1e-12, p + ".fi.w", p + ".fi.b", inter, gelu=True)
         return self.ln(ao, x, p + ".ln1.w", p + ".ln1.b", H, ph, p + ".ao.b")
 
-    def ffn_block(self, p, x, H, inter, ph, ti=".fi", to=".fo", tl=".ln2"):
-        """dense+GELU -> dense -> dropout -> LN(+x)   (vilbert_dialog.py:445-462)"""
-        a = self.lin(x, p + ti + ".w", p + ti + ".b", inter, H, gelu=True)
+    def ffn_block(self, p, x, H, inter, ph, ti=".fi", to=".fo", tl=".ln2", a=None):
+        """dense+GELU -> dense -> dropout -> LN(+x)   (vilbert_dialog.py:445-462); `a`: the first Linear's output when the caller
+        issued it with the LayerNorm in front (ln_lin)."""
+        if a is None:
+            a = self.lin(x, p + ti + ".w", p + ti + ".b", inter, H, gelu=True)
         fo = self.lin(a, p + to + ".w", p + to + ".b", H, inter)
         return self.ln(fo, x, p + tl + ".w", p + tl + ".b", H, ph, p + to + ".b")
 
@@ -786,11 +816,13 @@ class Engine(object):
             ctx2 = self.attn((qkv1, 0), (qkv2, Hb), (qkv2, 2 * Hb), Bn, nh, R, T, d, I["tmask"], False, -10000.0,
                              c.attention_probs_dropout_prob, label=p + ".attn2")
             hv = self.lin(ctx2, p + ".d1.w", p + ".d1.b", Hv, Hb)
-            av = self.ln(hv, xv, p + ".ln1.w", p + ".ln1.b", Hv, c.v_hidden_dropout_prob, p + ".d1.b")
-            ov = self.ffn_block(p, av, Hv, c.v_intermediate_size, c.v_hidden_dropout_prob, ".vfi", ".vfo", ".vln")
+            av, a = self.ln_lin(hv, xv, p + ".ln1.w", p + ".ln1.b", Hv, c.v_hidden_dropout_prob, p + ".d1.b", 1e-12,
+                                p + ".vfi.w", p + ".vfi.b", c.v_intermediate_size, gelu=True)
+            ov = self.ffn_block(p, av, Hv, c.v_intermediate_size, c.v_hidden_dropout_prob, ".vfi", ".vfo", ".vln", a=a)
         ht = self.lin(ctx1, p + ".d2.w", p + ".d2.b", H, Hb)
-        at = self.ln(ht, xt, p + ".ln2.w", p + ".ln2.b", H, c.hidden_dropout_prob, p + ".d2.b")
-        ot = self.ffn_block(p, at, H, c.intermediate_size, c.hidden_dropout_prob, ".tfi", ".tfo", ".tln")
+        at, a = self.ln_lin(ht, xt, p + ".ln2.w", p + ".ln2.b", H, c.hidden_dropout_prob, p + ".d2.b", 1e-12,
+                            p + ".tfi.w", p + ".tfi.b", c.intermediate_size, gelu=True)
+        ot = self.ffn_block(p, at, H, c.intermediate_size, c.hidden_dropout_prob, ".tfi", ".tfo", ".tln", a=a)
         return ov, ot
 
     def encoder(self, I):
@@ -808,15 +840,15 @@ class Engine(object):
             self.mark((kind, i))
             if kind == "t":
                 p = "t%d" % i
-                x1 = self.self_block(p, xt, Bn, T, c.hidden_size, c.num_attention_heads, I["tmask"],
-                                     c.attention_probs_dropout_prob, c.hidden_dropout_prob)
-                xt = self.ffn_block(p, x1, c.hidden_size, c.intermediate_size, c.hidden_dropout_prob)
+                x1, a = self.self_block(p, xt, Bn, T, c.hidden_size, c.num_attention_heads, I["tmask"],
+                                        c.attention_probs_dropout_prob, c.hidden_dropout_prob, inter=c.intermediate_size)
+                xt = self.ffn_block(p, x1, c.hidden_size, c.intermediate_size, c.hidden_dropout_prob, a=a)
             elif kind == "v":
                 p = "v%d" % i
                 with self.on("v"):
-                    x1 = self.self_block(p, xv, Bn, R, c.v_hidden_size, c.v_num_attention_heads, I["vmask"],
-                                         c.v_attention_probs_dropout_prob, c.v_hidden_dropout_prob)
-                    xv = self.ffn_block(p, x1, c.v_hidden_size, c.v_intermediate_size, c.v_hidden_dropout_prob)
+                    x1, a = self.self_block(p, xv, Bn, R, c.v_hidden_size, c.v_num_attention_heads, I["vmask"],
+                                            c.v_attention_probs_dropout_prob, c.v_hidden_dropout_prob, inter=c.v_intermediate_size)
+                    xv = self.ffn_block(p, x1, c.v_hidden_size, c.v_intermediate_size, c.v_hidden_dropout_prob, a=a)
             else:
                 xv, xt = self.conn_layer("c%d" % i, xv, xt, Bn, R, T, I)
         self.sync("t", "v")                   # join before VLFusion

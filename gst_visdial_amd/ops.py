@@ -834,10 +834,17 @@ def gemm_ln_bwd(ln_kw, dy, partial, nblk, B, C_out, N, *, dres=None, dx=None, b_
     return C_out
 
 
+LN_FOLD_MAX_H = int(os.environ.get("GSTVD_LN_FOLD_MAX_H", "768"))
+
+
 def gemm_ln_ok(M, N, H, dtype):
-    """Shapes the LayerNorm-folded GEMMs take (csrc/gemm_rows.hip): bf16, H = K a multiple of 64 up to 768, up to 640 rows
-    (beyond that the plain kernels' larger tiles win), at least five 128-column tiles."""
-    if not (dtype == torch.bfloat16 and H % 64 == 0 and H <= 768 and M <= 640 and N >= 640 and N % 8 == 0):
+    """Shapes the engine gives to the LayerNorm-folded GEMMs (csrc/gemm_rows.hip): bf16, H = K a multiple of 64 up to
+    GSTVD_LN_FOLD_MAX_H = 768 (the decoder's sites), up to 640 rows (beyond that the plain kernels' larger tiles win), at least
+    five 128-column tiles.  The kernel itself takes H up to 1024 since round 5 (the vision stream's width; GSTVD_LN_FOLD_MAX_H=1024
+    sends its 36 sites there): bit-identical, but an 80 KB / 512-thread workgroup does not fit beside the text stream's
+    workgroups the way the 48 KB 64-tile GEMM + the LayerNorm kernel do -- 12.35 -> 12.66 ms per step
+    (profiles/r05_ln_fold_vision_ab.txt), so the default keeps the vision sites on the separate kernels."""
+    if not (dtype == torch.bfloat16 and H % 64 == 0 and H <= LN_FOLD_MAX_H and M <= 640 and N >= 640 and N % 8 == 0):
         return False
     # one round of the chip: two workgroups (16 rows x 128 columns) fit a CU; beyond 512 the second round doubles the launch
     # (N = 3072 at 400 rows: 22 us forward / 38 us backward against 23 / 26 us for the two separate kernels)

@@ -768,7 +768,10 @@ def test_skinny_decode_gemm(M, N, K, out):
 # ---- round 3: LayerNorm folded into the Linear next to it (csrc/gemm_rows.hip), decoder row counts --------------------------
 @pytest.mark.parametrize("M,N,H,p,b_km,gelu", [(400, 768, 768, 0.3, False, False), (400, 3072, 768, 0.25, False, True),
                                                (250, 2304, 768, 0.0, False, False), (77, 648, 128, 0.3, False, False),
-                                               (400, 768, 768, 0.3, True, False)])
+                                               (400, 768, 768, 0.3, True, False),
+                                               # round 5: the vision stream's width (H = 1024: four 256-column vectors per row)
+                                               (592, 1024, 1024, 0.1, False, True), (370, 3072, 1024, 0.1, False, False),
+                                               (100, 896, 832, 0.2, True, False)])
 def test_layernorm_folded_into_the_next_linear_forward(M, N, H, p, b_km, gelu):
     """gstvd_gemm_ln_fwd == gstvd_ln_fwd followed by gstvd_gemm: the normalised rows / mean / rstd it writes are BIT-identical to
     the stand-alone LayerNorm kernel's (same arithmetic in the same order), the product equals the two-launch result (same bf16
@@ -795,12 +798,12 @@ def test_layernorm_folded_into_the_next_linear_forward(M, N, H, p, b_km, gelu):
     o.ln_fwd(**k1)
     o.gemm(k1["y"], wk, c1, M, N, H, b_km=b_km, bias=bias, aux=u1, epi=epi)
     # (gemm_ln_ok is the ENGINE's policy -- shapes whose grid is a single round of the chip; the kernel itself takes all of these)
-    assert o.gemm_ln_ok(M, N, H, bf) == (((M + 15) // 16) * ((N + 127) // 128) <= 512)
+    assert o.gemm_ln_ok(M, N, H, bf) == (((M + 15) // 16) * ((N + 127) // 128) <= 512 and H <= o.LN_FOLD_MAX_H)
     o.gemm_ln_fwd(k2, wk, c2, N, b_km=b_km, bias=bias, aux=u2, epi=epi)
     assert torch.equal(k1["y"], k2["y"]) and torch.equal(k1["mean"], k2["mean"])
     # (H = 768, the decoder's width, runs the same three-vector code as ln_fwd's instantiation: bit-equal; narrower rows take
     # another instantiation there, whose fused-multiply-add contraction may differ in the last bit of the variance)
-    assert torch.equal(k1["rstd"], k2["rstd"]) if H == 768 else torch.allclose(k1["rstd"], k2["rstd"], rtol=1e-6, atol=0)
+    assert torch.equal(k1["rstd"], k2["rstd"]) if H in (768, 1024) else torch.allclose(k1["rstd"], k2["rstd"], rtol=1e-6, atol=0)
     assert torch.equal(c1, c2)
     if gelu:
         assert torch.equal(u1, u2)
@@ -811,7 +814,9 @@ def test_layernorm_folded_into_the_next_linear_forward(M, N, H, p, b_km, gelu):
 
 
 @pytest.mark.parametrize("M,N,H,p,dgelu,add", [(400, 768, 768, 0.3, False, True), (400, 3072, 768, 0.25, True, False),
-                                               (250, 768, 768, 0.0, False, False), (77, 648, 128, 0.3, False, True)])
+                                               (250, 768, 768, 0.0, False, False), (77, 648, 128, 0.3, False, True),
+                                               (592, 1024, 1024, 0.1, True, False), (592, 1024, 1024, 0.1, False, True),
+                                               (100, 896, 832, 0.2, False, False)])
 def test_layernorm_backward_folded_into_the_producers_input_gradient(M, N, H, p, dgelu, add):
     """gstvd_gemm_ln_bwd == gstvd_ln_bwd followed by the input-gradient GEMM of the Linear that produced the LayerNorm's input
     (C = dx . W, W row-major [H, N] = k-major B): dres / dx bit-identical to the stand-alone kernel, the product equal to the
