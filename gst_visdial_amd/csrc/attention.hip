@@ -503,7 +503,7 @@ __global__ __launch_bounds__(256, (D <= 64 ? 3 : 2)) void attn_fwd_kernel(gstvd_
 // backward, part 1: dQ (and delta = rowsum(dO * O)); same tiling as forward
 // =====================================================================================================
 template <typename T, int D, bool E32>
-DEVFN void attn_bwd_dq_body(const gstvd_attn_t& a, const int bx, char* smem) {
+DEVFN void attn_bwd_dq_body(const gstvd_attn_t& a, const int bx, const int h, const int b, char* smem) {
   constexpr bool BF = Img<T, D>::BF;
   constexpr int TP = D <= 64 ? 2 : 1;                         // 16-key tiles per inner iteration
   char* sKr = smem;                                           // row image of K
@@ -511,7 +511,6 @@ DEVFN void attn_bwd_dq_body(const gstvd_attn_t& a, const int bx, char* smem) {
   char* sVr = smem + (BF ? 2 : 1) * Img<T, D>::BYTES;         // row image of V
   float* smask = (float*)(smem + (BF ? 3 : 2) * Img<T, D>::BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
-  const int b = blockIdx.z, h = blockIdx.y;
   const int q = bx * 64 + wave * 16 + li;
   const bool qv = q < a.Lq;
   const T* Qb = (const T*)a.Q + (int64_t)b * a.Lq * a.ldq + h * D;
@@ -610,7 +609,7 @@ DEVFN void attn_bwd_dq_body(const gstvd_attn_t& a, const int bx, char* smem) {
 // backward, part 2: dK and dV; one wave owns 16 keys, queries stream through LDS
 // =====================================================================================================
 template <typename T, int D, bool E32>
-DEVFN void attn_bwd_dkv_body(const gstvd_attn_t& a, const int bx, char* smem) {
+DEVFN void attn_bwd_dkv_body(const gstvd_attn_t& a, const int bx, const int h, const int b, char* smem) {
   constexpr bool BF = Img<T, D>::BF;
   constexpr int IB = Img<T, D>::BYTES;
   constexpr int TP = D <= 64 ? 2 : 1;                         // 16-query tiles per inner iteration
@@ -621,7 +620,6 @@ DEVFN void attn_bwd_dkv_body(const gstvd_attn_t& a, const int bx, char* smem) {
   float* sLse = (float*)(smem + (BF ? 4 : 2) * IB);
   float* sDel = sLse + 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
-  const int b = blockIdx.z, h = blockIdx.y;
   const int key = bx * 64 + wave * 16 + li;
   const bool kv = key < a.Lk;
   const T* Ob = (const T*)a.O + (int64_t)b * a.Lq * a.ldo + h * D;
@@ -996,21 +994,32 @@ template <typename T, int D> static int attn_fwd_launch(const gstvd_attn_t& a, h
   GSTVD_LAUNCH_CHECK();
   return 0;
 }
-// One launch for the whole backward: blocks [0, nkb) own 64 keys each (dK, dV), blocks [nkb, nkb + nqb) own 64 queries each (dQ).
-// The dK/dV blocks come first: they are the longer ones (two second products per tile).
+// One launch for the whole backward: per (row, head) nkb blocks own 64 keys each (dK, dV: they walk the queries in nqb chunks) and
+// nqb blocks own 64 queries each (dQ: they walk the keys in nkb chunks).  A 1-D grid, ALL blocks of the longer-running class first
+// (round 5): with the classes interleaved per (row, head) -- blockIdx.x over both -- the grid of the few-query / few-key shapes is
+// 1.25-1.5 rounds of the chip's resident workgroups, so the long blocks of the last (row, head)s started when the first short ones
+// retired and the launch took the SUM of the two classes' times (decoder cross-attention 25 x 293: 23.8 us for 14.1 us of dK/dV
+// blocks alone and 12.5 us of dQ blocks alone; profiles/r05_attn_block_order.txt).  Long ones first, the short ones fill in behind.
 template <typename T, int D>
-__global__ __launch_bounds__(256, (D <= 64 ? 3 : 2)) void attn_bwd_kernel(gstvd_attn_t a, int nkb) {
+__global__ __launch_bounds__(256, (D <= 64 ? 3 : 2)) void attn_bwd_kernel(gstvd_attn_t a, int nkb, int nqb, int dq_first) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int bx = blockIdx.x;
+  const int nbh = a.nh * a.B;
+  int id = blockIdx.x;
+  const int nfirst = (dq_first ? nqb : nkb) * nbh;
+  const bool second = id >= nfirst;
+  if (second) id -= nfirst;
+  const bool is_dq = (dq_first != 0) != second;
+  const int per = is_dq ? nqb : nkb;
+  const int bx = id % per, bh = id / per, h = bh % a.nh, b = bh / a.nh;
   if constexpr (sizeof(T) == 2) {
     if (attn_small_index_space(a)) {
-      if (bx < nkb) attn_bwd_dkv_body<T, D, true>(a, bx, smem);
-      else attn_bwd_dq_body<T, D, true>(a, bx - nkb, smem);
+      if (!is_dq) attn_bwd_dkv_body<T, D, true>(a, bx, h, b, smem);
+      else attn_bwd_dq_body<T, D, true>(a, bx, h, b, smem);
       return;
     }
   }
-  if (bx < nkb) attn_bwd_dkv_body<T, D, false>(a, bx, smem);
-  else attn_bwd_dq_body<T, D, false>(a, bx - nkb, smem);
+  if (!is_dq) attn_bwd_dkv_body<T, D, false>(a, bx, h, b, smem);
+  else attn_bwd_dq_body<T, D, false>(a, bx, h, b, smem);
 }
 
 static bool attn_small_index_space_host(const gstvd_attn_t& a) {
@@ -1043,8 +1052,12 @@ template <typename T, int D> static int attn_bwd_launch(const gstvd_attn_t& a, h
   static int rc = attn_lds_attr(attn_bwd_kernel<T, D>, lds);
   if (rc) return rc;
   const int nkb = (a.Lk + 63) / 64, nqb = (a.Lq + 63) / 64;
-  dim3 grid((unsigned)(nkb + nqb), (unsigned)a.nh, (unsigned)a.B);
-  hipLaunchKernelGGL((attn_bwd_kernel<T, D>), grid, dim3(256), lds, s, a, nkb);
+  // a dQ block walks nkb key chunks, a dK/dV block nqb query chunks (with two second products per tile: the longer one at a tie);
+  // GSTVD_ATTN_BWD_ORDER=0: the interleaved order of rounds 1-4 is not kept -- 1 forces dK/dV first, 2 dQ first (A/B)
+  static const int order = [] { const char* e = getenv("GSTVD_ATTN_BWD_ORDER"); return e ? atoi(e) : 0; }();
+  const int dq_first = order == 1 ? 0 : order == 2 ? 1 : (nkb > nqb ? 1 : 0);
+  dim3 grid((unsigned)((nkb + nqb) * a.nh * a.B));
+  hipLaunchKernelGGL((attn_bwd_kernel<T, D>), grid, dim3(256), lds, s, a, nkb, nqb, dq_first);
   GSTVD_LAUNCH_CHECK();
   return 0;
 }

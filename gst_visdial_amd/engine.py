@@ -484,19 +484,9 @@ class Engine(object):
             # the two full-chip kernels do not share the chip profitably; profiles/r03_chunk_sweep.txt.  Not kept.)
             with torch.cuda.stream(self.aux):
                 fused = self.wgrads.flush(fuse=self.pipe.fuse_handle())
-            if os.environ.get("GSTVD_COLSUM_SIDE", "0") == "1":
-                # (A/B, round 5: the same reductions from the vision stream -- does the graph executor then start the grouped
-                # launch without waiting for them?)
-                ev = torch.cuda.Event()
-                ev.record(self.main)
-                self.side.wait_event(ev)
-                with torch.cuda.stream(self.side):
-                    self.colsums.flush()
-                ev = torch.cuda.Event()
-                ev.record(self.side)
-                self.main.wait_event(ev)
-            else:
-                self.colsums.flush()
+            # (issuing these reductions from the vision stream instead does not let the grouped launch start earlier:
+            # 12.30 / 12.34 vs 12.31 / 12.35 ms, tools/r05_s14.sh)
+            self.colsums.flush()
             ev = torch.cuda.Event()
             ev.record(self.main)
             self.aux.wait_event(ev)

@@ -274,6 +274,12 @@ def test_full_size_step_with_the_fused_update_is_bit_identical_to_the_two_launch
     for k in ("param", "m", "v", "shadow"):
         a, b = ref[k], got[k]
         assert torch.equal(a[det], b[det]), (k, (a.float() - b.float())[det].abs().max().item(), int((a != b)[det].sum()))
-        assert (a.float() - b.float()).abs().max().item() < 1e-6, k
+        # (atomically accumulated tables: the last fp32 bits follow the order of the atomic adds, which can flip the rounding of a bf16
+        # shadow weight -- one ulp there, see the model-level test above)
+        d = (a.float() - b.float()).abs()
+        if k == "shadow" and a.dtype == torch.bfloat16:
+            assert bool((d <= a.float().abs() * 2.0 ** -7 + 1e-6).all()), k
+        else:
+            assert d.max().item() < 1e-6, k
     assert got["nfused"] > 0.9 * got["n"], (got["nfused"], got["n"])
     assert not torch.equal(ref["param"], ref["shadow"].float())        # (sanity: fp32 masters differ from their bf16 shadows)
