@@ -38,7 +38,7 @@ python3 bench.py --steps 10 --warmup 2 --rows-per-gpu 10 --no-cpu-baseline --no-
 tail -4 $out/bench_launch_paths.txt | cut -c1-300; cut -c1-200 $out/bench_force_dist_legs.json
 # 9. whole-step A/B records of the switches that stayed (two interleaved rounds each)
 ( bash tools/r04_step_ab.sh GSTVD_GROUP_ORDER 0 1; bash tools/r04_step_ab.sh GSTVD_ATTN_ONEPASS 0 1; bash tools/r04_step_ab.sh GSTVD_GEMM64_NS 8 3
-  bash tools/r04_step_ab.sh GSTVD_ATTN_KEEP_BITS 0 1; bash tools/r04_step_ab.sh GSTVD_FUSE_UPDATE 0 1 ) > $out/step_ab.txt 2>&1; cat $out/step_ab.txt
+  bash tools/r04_step_ab.sh GSTVD_ATTN_KEEP_BITS 0 1; bash tools/r04_step_ab.sh GSTVD_ATTN_BWD_ORDER 1 0; bash tools/r04_step_ab.sh GSTVD_FUSE_UPDATE 0 1 ) > $out/step_ab.txt 2>&1; cat $out/step_ab.txt
 # 10. eval / decode side measurements (decode with and without the questioner's 4-gram ban)
 python3 tools/eval_decode_bench.py > $out/eval_decode.json 2> /dev/null; cat $out/eval_decode.json
 # 11. 10 clean fresh-process runs of the 1-rank RCCL captured step, all-reduce and sharded update
