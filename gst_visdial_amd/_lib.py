@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgstvd_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 F32, BF16 = 0, 1
 EPI_BIAS, EPI_ADD, EPI_GELU, EPI_DGELU, EPI_DROPOUT = 1, 2, 4, 8, 16
@@ -60,7 +60,8 @@ class SampleDesc(C.Structure):
     _fields_ = [("logits", _vp), ("ld", _i64), ("dtype", _i32), ("B", _i32), ("V", _i32), ("top_k", _i32), ("temperature", _f32),
                 ("u", _vp), ("out", _vp), ("out_stride", _i64), ("banned", _vp), ("banned_ld", _i64),
                 ("hist", _vp), ("hist_ld", _i64), ("hist_T", _i32), ("ngram", _i32),
-                ("ids_tm", _vp), ("ids_stride", _i64), ("cur_len", _i32), ("n_special", _i32), ("special", _i32 * 8)]
+                ("ids_tm", _vp), ("ids_stride", _i64), ("cur_len", _i32), ("n_special", _i32), ("special", _i32 * 8),
+                ("top_p", _f32), ("reserved_", _i32)]
 
 
 class AdamFuse(C.Structure):

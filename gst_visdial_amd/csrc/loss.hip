@@ -202,7 +202,7 @@ extern "C" int gstvd_vl_split(const void* d_enc, int64_t B, int64_t R, int64_t T
 
 // 2: gstvd_ln_bwd_t.nblk (round 2); 3: gstvd_gemm_ln_fwd / _bwd, debug entry gone (round 3); 4: gstvd_gemm_grouped_adamw,
 // gstvd_adamw_blocks (round 4); 5: block_map_dev / nblocks of the grouped launches (round 5)
-extern "C" int gstvd_abi_version(void) { return 5; }
+extern "C" int gstvd_abi_version(void) { return 6; }
 extern "C" const char* gstvd_build_arch(void) { return "gfx950"; }
 
 extern "C" int gstvd_ce_fwd(const void* logits, int64_t ldl, const int64_t* labels, int64_t M, int64_t V, int64_t ignore_index,

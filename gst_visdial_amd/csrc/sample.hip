@@ -1,6 +1,8 @@
 // One sampling step of the decode loop on the device (models/visual_dialog_model.py:96-108, utils/decoding_utils.py:4-35):
 //   z = logits / temperature  (banned tokens of the n-gram filter: -inf)
 //   top-k: z < (k-th largest z) -> -inf   (ties with the k-th value stay, like the reference's `logits < topk(...)[..., -1]`)
+//   top-p (utils/decoding_utils.py:22-34): a token stays when the probability mass of the tokens sorted in FRONT of it is <= top_p
+//          (the reference removes `cumsum(softmax(sorted)) > top_p` shifted right by one, so the token that crosses top_p stays)
 //   p = softmax(z);  id = first index whose cumulative probability reaches u * sum(p)   (inverse CDF, decoding.draw_from_uniform)
 // One workgroup per dialog row, the row's V scaled logits live in LDS (V = 30522: 119 KB of the CU's 160 KB).  It replaces
 // ~25 small library kernels per step (topk's multi-block radix passes, softmax, cumsum scans, compares, copies) by one launch,
@@ -11,6 +13,9 @@
 namespace {
 
 constexpr int NT = 1024, NWV = NT / 64;
+// up to here top-k walks the distinct values from the top (one block reduction per value: 33 us at k = 7, 120 us at k = 64 for
+// 16 x 30522 bf16), beyond it bisects on the value (52 us whatever k; profiles/r05_sample_top_p.txt)
+constexpr int TOPK_ITERATIVE_MAX = 16;
 
 // block reduction of (max value, how many elements carry it); counts travel as floats (exact below 2^24)
 DEVFN void reduce_maxcount(float& m, int& c, float* smf, float* smc, int tid) {
@@ -31,6 +36,22 @@ DEVFN void reduce_maxcount(float& m, int& c, float* smf, float* smc, int tid) {
     }
   }
   m = bm; c = (int)bc;
+}
+
+// order-preserving integer key of a float (larger value <-> larger key; -inf is the smallest key of a non-NaN value)
+DEVFN uint32_t fkey(float f) { const uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+DEVFN float fkey_inv(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+// block sum of one float per thread, the same value in every thread
+DEVFN float block_sum(float x, float* smf, int tid) {
+  const float w = wave_sum(x);
+  __syncthreads();
+  if ((tid & 63) == 0) smf[tid >> 6] = w;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < NWV; ++i) t += smf[i];
+  return t;
 }
 
 template <typename T>
@@ -106,7 +127,21 @@ __global__ __launch_bounds__(NT) void sample_topk_kernel(gstvd_sample_t a) {
   reduce_maxcount(m, c, smf, smc, tid);                      // (also orders the z[] writes before the reads below)
   const float zmax = m;
   float kth = -INFINITY;
-  if (a.top_k > 0) {
+  if (a.top_k > TOPK_ITERATIVE_MAX && a.top_k < V && c < a.top_k) {
+    // large k: bisection over the float keys for the k-th largest value = the largest t with #{z >= t} >= k (at most 32 counts
+    // of the row instead of up to k rounds of "next smaller distinct value"); fewer than k finite values -> -inf (nothing goes)
+    uint32_t lo = fkey(-INFINITY), hi = fkey(zmax);            // #{z >= val(lo)} = V >= k;  #{z >= val(hi)} = c < k
+    while (hi - lo > 1u) {                                     // uniform: every thread holds the same (lo, hi)
+      const uint32_t mid = lo + ((hi - lo) >> 1);
+      const float t = fkey_inv(mid);
+      float n = 0.f;
+#pragma unroll
+      for (int j = 0; j < SEG; ++j) n += (tid + j * NT < V && zr[j] >= t) ? 1.f : 0.f;
+      n = block_sum(n, smf, tid);                              // (exact: counts stay below 2^24)
+      if (n >= (float)a.top_k) lo = mid; else hi = mid;
+    }
+    kth = fkey_inv(lo);
+  } else if (a.top_k > 0) {
     const int k = a.top_k < V ? a.top_k : V;
     int have = c;
     float thr = m;
@@ -127,6 +162,29 @@ __global__ __launch_bounds__(NT) void sample_topk_kernel(gstvd_sample_t a) {
       have += c2;
     }
     kth = thr;
+  }
+  if (a.top_p > 0.f && a.top_p < 1.f) {
+    // top-p on what top-k left: with w_i = [z_i >= kth] exp(z_i - zmax) and S = sum w, token i stays iff the mass of the strictly
+    // larger logits G(z_i) = sum_{z_j > z_i} w_j is <= top_p S.  G is a falling step function of the threshold, so the kept set
+    // is {z >= t*} with t* the smallest value whose G is <= top_p S: bisection over the float keys, one masked sum of the row per
+    // step (<= 32).  Equal logits stay or go together (the reference's sort leaves the order inside a tie to the sort).
+    float sw = 0.f;
+#pragma unroll
+    for (int j = 0; j < SEG; ++j) sw += (zr[j] >= kth && zr[j] > -INFINITY) ? __expf(zr[j] - zmax) : 0.f;
+    const float target = a.top_p * block_sum(sw, smf, tid);
+    uint32_t lo = fkey(kth) - 1u, hi = fkey(zmax);             // G(val(hi)) = 0 <= target; below kth nothing is left to drop
+    if (!(kth > -INFINITY)) lo = fkey(-INFINITY);
+    while (hi - lo > 1u) {
+      const uint32_t mid = lo + ((hi - lo) >> 1);
+      const float t = fkey_inv(mid);
+      float g = 0.f;
+#pragma unroll
+      for (int j = 0; j < SEG; ++j) g += (zr[j] >= kth && zr[j] > t) ? __expf(zr[j] - zmax) : 0.f;
+      g = block_sum(g, smf, tid);
+      if (g <= target) hi = mid; else lo = mid;
+    }
+    const float pth = fkey_inv(hi);
+    if (pth > kth) kth = pth;
   }
   // inverse CDF over e_i = [z_i >= kth] * exp(z_i - zmax): thread t owns the contiguous segment [t * seg, (t + 1) * seg)
   // (seg odd: the threads' LDS reads fall into different banks); the segment's weights stay in registers for the second pass
@@ -203,7 +261,7 @@ template <typename T> int launch(const gstvd_sample_t& a, hipStream_t s) {
 extern "C" int gstvd_sample_topk(const gstvd_sample_t* a, gstvd_stream_t stream) {
   if (!a || !a->logits || !a->u || !a->out) return GSTVD_E_NULL;
   if (a->dtype != GSTVD_F32 && a->dtype != GSTVD_BF16) return GSTVD_E_DTYPE;
-  if (a->B <= 0 || a->V <= 0 || a->ld < a->V || a->top_k < 0 || !(a->temperature > 0.f)) return GSTVD_E_SHAPE;
+  if (a->B <= 0 || a->V <= 0 || a->ld < a->V || a->top_k < 0 || !(a->temperature > 0.f) || !(a->top_p >= 0.f)) return GSTVD_E_SHAPE;
   if (a->V > 31 * 1024) return GSTVD_E_UNSUPPORTED;                         // the row must fit the CU's LDS (and 31 weights per thread)
   if (a->ngram > 0 && (!a->hist || !a->ids_tm || a->hist_T < 0 || a->cur_len < 0 || a->n_special < 0 || a->n_special > 8 || a->ids_stride < a->B))
     return a->hist && a->ids_tm ? GSTVD_E_SHAPE : GSTVD_E_NULL;

@@ -1190,9 +1190,9 @@ class Engine(object):
     @staticmethod
     def _fused_sampling(P, vocab):
         """The fused sampling kernel covers the reference's settings (generate.py:138-141,177-180: top_k 7, top_p 0; BERT's
-        30522-token vocabulary); top-p, a very wide top-k or a vocabulary beyond one CU's LDS take the torch-op form of the
-        filters, issued eagerly step by step (no captured token graph)."""
-        return P["top_p"] <= 0.0 and P["top_k"] <= ops.SAMPLE_MAX_TOP_K and vocab <= ops.SAMPLE_MAX_VOCAB
+        30522-token vocabulary) and, since ABI 6, any top_k and top_p; only a vocabulary beyond one CU's LDS takes the torch-op
+        form of the filters, issued eagerly step by step (no captured token graph)."""
+        return vocab <= ops.SAMPLE_MAX_VOCAB        # (any top_k, any top_p: both filters run inside the sampling launch since ABI 6)
 
     @staticmethod
     def _sampling_step(logits, cur, pos, hist, P, u_row):
@@ -1206,7 +1206,7 @@ class Engine(object):
             # the n-gram ban (utils/decoding_utils.py:38-77) runs inside the sampling launch: `hist` and the time-major id buffer
             # are all it needs (round 4 built a [B, V + 1] mask with ten torch launches per token: +2 ms per questioner decode)
             ops.sample_topk(logits, P["temperature"], P["top_k"], u_row, cur[pos], None,
-                            ngram=(hist, cur, pos, P["ngram"]) if P["ngram"] > 0 else None)
+                            ngram=(hist, cur, pos, P["ngram"]) if P["ngram"] > 0 else None, top_p=P["top_p"])
             return
         last = logits.float() / P["temperature"]
         last = decoding.batch_ngram_blocking(last, hist, cur[:pos].t(), ngram_size=P["ngram"])

@@ -675,15 +675,16 @@ def ce_bwd(logits, labels, lse, stats, gscale, mean, M, V, dlogits, ignore_index
     _prof_end(e0, "ce_bwd", 0.0, float(M) * V * (logits.element_size() + dlogits.element_size()), (M, V))
 
 
-SAMPLE_MAX_TOP_K = 64      # beyond this (or with top-p) the filter runs as torch ops (decoding.batch_top_k_top_p_sampling)
+SAMPLE_MAX_TOP_K = 1 << 30  # (ABI 6: no limit any more -- k <= 16 walks the distinct values from the top, larger k bisects; top-p is in the kernel too)
 SAMPLE_MAX_VOCAB = 31 * 1024   # a row of scaled logits lives in one CU's LDS (and 31 registers per thread)
 
 
 SPECIAL_TOKEN_IDS = (0, 100, 101, 102, 103)      # utils/decoding_utils.py:38 (the default no reference caller overrides)
 
 
-def sample_topk(logits, temperature, top_k, u, out, banned=None, ngram=None):
-    """One sampling step (gstvd_sample_topk): out[b] <- inverse-CDF draw from softmax(top_k(logits / temperature, banned -> -inf)).
+def sample_topk(logits, temperature, top_k, u, out, banned=None, ngram=None, top_p=0.0):
+    """One sampling step (gstvd_sample_topk): out[b] <- inverse-CDF draw from softmax(top_p(top_k(logits / temperature, banned -> -inf))).
+    top_p in (0, 1): nucleus filtering (utils/decoding_utils.py:22-34) inside the launch; 0 / >= 1: off.
     logits [B, V] fp32 / bf16 (row stride free); u [B] fp32 in (0, 1); out: int64 view with B elements (any stride, e.g. a
     column of the id buffer); banned: None or bool / uint8 [B, >= V].
     ngram = (hist [B, T] int64, ids_tm [L, B] int64 time-major, cur_len, n[, special ids]): the n-gram filter of
@@ -692,6 +693,7 @@ def sample_topk(logits, temperature, top_k, u, out, banned=None, ngram=None):
     Bn, V = logits.shape
     d = L.SampleDesc()
     d.logits, d.ld, d.dtype, d.B, d.V, d.top_k, d.temperature = _p(logits), logits.stride(0), dt(logits), Bn, V, int(top_k), float(temperature)
+    d.top_p = float(top_p)
     if u.dtype != torch.float32 or not u.is_contiguous() or u.numel() != Bn:
         raise L.GstvdError("sample_topk: u must be a contiguous fp32 vector of B uniforms")
     if out.dtype != torch.int64 or out.numel() != Bn or logits.stride(1) != 1:

@@ -256,12 +256,17 @@ int gstvd_answer_scores(const void* logits, int64_t ldl, const float* lse, const
  * (int64 ids, row stride hist_ld; n-grams that contain one of the n_special ids in `special` are ignored) and whose first n-1
  * tokens are the row's last n-1 generated ids: ids_tm[(cur_len - (n-1) + j) * ids_stride + b], j < n-1, read from the TIME-MAJOR
  * id buffer [positions, ids_stride >= B].  Nothing is banned while cur_len < n-1 or hist_T < n (the reference's slice
- * semantics).  It composes with `banned` (either bans). */
+ * semantics).  It composes with `banned` (either bans).
+ * top_p in (0, 1) (ABI 6): nucleus filtering after top-k, utils/decoding_utils.py:22-34 -- a token stays when the softmax mass of
+ * the tokens sorted in front of it (strictly larger logits) is <= top_p, i.e. the token that crosses top_p stays; equal logits
+ * stay or go together (the reference leaves the order inside a tie to torch.sort).  0 or >= 1: off.  top_k is unbounded since
+ * ABI 6 (k <= 16 walks the distinct values from the top, larger k bisects on the value). */
 typedef struct {
   const void* logits; int64_t ld; int32_t dtype; int32_t B; int32_t V; int32_t top_k; float temperature;
   const float* u; int64_t* out; int64_t out_stride; const uint8_t* banned; int64_t banned_ld;
   const int64_t* hist; int64_t hist_ld; int32_t hist_T; int32_t ngram;
   const int64_t* ids_tm; int64_t ids_stride; int32_t cur_len; int32_t n_special; int32_t special[8];
+  float top_p; int32_t reserved_;                                       /* ABI 6 */
 } gstvd_sample_t;
 int gstvd_sample_topk(const gstvd_sample_t* a, gstvd_stream_t s);
 

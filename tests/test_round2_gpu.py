@@ -127,9 +127,11 @@ def test_bf16_decode_step_with_folded_layernorms_matches_the_unfolded_plan_and_f
     assert (outs["separate"] - outs["fp32"]).abs().max().item() <= 0.1 * max(1.0, scale)
 
 
-def test_top_p_decode_takes_the_unfused_eager_path():
-    """top-p (not used by the reference's scripts, generate.py:138-141) is outside the fused sampling kernel: the filters run
-    as torch ops step by step, nothing is captured, and the ids are those of the oracle's torch-op restatement."""
+def test_top_p_decode_runs_in_the_fused_kernel_and_equals_the_torch_filters():
+    """top-p (not used by the reference's scripts, generate.py:138-141; utils/decoding_utils.py:22-34) runs inside the sampling
+    kernel since ABI 6: the decode is captured like any other, and its ids are those of the torch-op form of the filters (the
+    path a vocabulary beyond the kernel's range still takes), step by step under the same uniforms."""
+    from gst_visdial_amd.engine import Engine
     s = sc()
     model, params, cfg = s.build_tiny_model("fp32", DEV, mode="vd_gen_val")
     model.eval()
@@ -138,13 +140,20 @@ def test_top_p_decode_takes_the_unfused_eager_path():
     args = dict(temperature=1.1, top_k=12, top_p=0.8, ngram_blocking_size=2, uniforms=u)
     a0 = model(**args, **_decode_kw(s, g))
     a1 = model(**args, **_decode_kw(s, g))
-    assert len(model.engine._decode_sessions) == 0 and torch.equal(a0, a1)
-    # the same settings without top-p go through the fused kernel (and get captured): top-p can only remove tokens, so
-    # wherever both runs drew from an unchanged distribution prefix they agree; at least the first token must be a top-12 one
+    assert len(model.engine._decode_sessions) == 1 and torch.equal(a0, a1)
+    keep = Engine.__dict__["_fused_sampling"]                                  # (the staticmethod object itself)
+    try:
+        Engine._fused_sampling = staticmethod(lambda P, vocab: False)          # the torch-op filters, eagerly
+        e0 = model(**args, **_decode_kw(s, g))
+        w0 = model(**dict(args, top_k=0, top_p=0.5), **_decode_kw(s, g))
+    finally:
+        Engine._fused_sampling = keep
+    assert torch.equal(a0, e0)
+    k0 = model(**dict(args, top_k=0, top_p=0.5), **_decode_kw(s, g))          # top-p alone (no top-k in front)
+    assert torch.equal(k0, w0)
     b0 = model(**dict(args, top_p=0.0), **_decode_kw(s, g))
-    assert len(model.engine._decode_sessions) == 1 and b0.shape == a0.shape
     V = model.decoder.config.vocab_size
-    assert ((a0 >= 0) & (a0 < V)).all() and ((b0 >= 0) & (b0 < V)).all()
+    assert b0.shape == a0.shape and ((a0 >= 0) & (a0 < V)).all() and ((b0 >= 0) & (b0 < V)).all()
     model.engine.close()
 
 

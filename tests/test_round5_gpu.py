@@ -333,3 +333,92 @@ def test_attention_keep_bits_equal_the_hashed_mask_and_the_backward_that_reads_t
     got = ((word >> (16 * ((ki & 15) >> 2) + (qi & 15))) & 1) != 0
     assert torch.equal(got, mask)
     assert 0.85 < mask.float().mean().item() < 0.95
+
+
+# ---- ABI 6: top-p and unbounded top-k inside the sampling kernel ----------------------------------------
+def _top_p_by_value(z, top_p):
+    """The kernel's rule in torch (double): a token stays when the softmax mass of the STRICTLY larger logits is <= top_p.  Without
+    ties this is utils/decoding_utils.py:22-34 (remove cumsum(softmax(sorted)) > top_p, shifted right by one)."""
+    p = torch.softmax(z.double(), -1)
+    sz, si = torch.sort(z.double(), descending=True, dim=-1)
+    sp = p.gather(-1, si)
+    front = torch.cumsum(sp, -1) - sp                                     # mass sorted in front of each position
+    first = torch.ones_like(sz, dtype=torch.bool)
+    first[:, 1:] = sz[:, 1:] != sz[:, :-1]                                # first position of every group of equal logits
+    above = torch.cummax(torch.where(first, front, torch.full_like(front, -1.0)), -1).values
+    keep = torch.zeros_like(first).scatter(-1, si, above <= top_p)
+    return z.masked_fill(~keep, float("-inf")), above.gather(-1, si.argsort(-1))
+
+
+def _assert_draws(got, z_filtered, u, what):
+    from gst_visdial_amd import decoding
+    prob = torch.softmax(z_filtered.double(), -1)
+    want = decoding.draw_from_uniform(prob.float(), u).view(-1)
+    assert (prob.gather(1, got[:, None]) > 0).all(), what                 # never a filtered token
+    c = torch.cumsum(prob, -1)
+    bad = 0
+    for b in (got != want).nonzero().view(-1).tolist():
+        lo, hi = sorted((int(got[b]), int(want[b])))
+        on_step = (abs(float(c[b, hi - 1] - c[b, lo])) if hi - 1 >= lo else 0.0) < 1e-5 and \
+            min(abs(float(c[b, lo]) - float(u[b])), abs(float(c[b, hi - 1]) - float(u[b]))) < 1e-5
+        assert on_step, (what, b, int(got[b]), int(want[b]))
+        bad += 1
+    assert bad <= 1, what
+
+
+@pytest.mark.parametrize("V", [97, 30522])
+def test_sampling_kernel_top_p_and_wide_top_k_equal_the_torch_filters(V):
+    """utils/decoding_utils.py:4-35 inside gstvd_sample_topk: top-p alone, behind a narrow and a wide top-k, k beyond the former
+    limit of 64 and beyond the vocabulary; fp32 logits without ties: the kept set equals the reference filter's
+    (decoding.batch_top_k_top_p_sampling = the reference's code path) wherever no token sits within 1e-6 of the top_p boundary,
+    and the drawn ids equal the inverse-CDF draw over it."""
+    from gst_visdial_amd import decoding, ops
+    Bn = 12
+    g = torch.Generator().manual_seed(1000 + V)
+    for case, (top_k, top_p, temp) in enumerate([(0, 0.9, 1.0), (0, 0.5, 0.7), (0, 0.05, 1.0), (7, 0.9, 0.7), (50, 0.8, 1.3), (200, 0.0, 1.0),
+                                                  (1000, 0.95, 0.8), (V + 5, 0.0, 1.0), (V + 5, 0.6, 1.0), (0, 1.0, 1.0), (65, 0.0, 1.0)]):
+        logits = (torch.randn(Bn, V, generator=g) * 2.0).to(DEV)
+        u = torch.rand(Bn, generator=g).clamp_min(1e-6).to(DEV)
+        got = torch.full((Bn,), -1, dtype=torch.long, device=DEV)
+        ops.sample_topk(logits, temp, top_k, u, got, None, top_p=top_p)
+        z = logits / temp
+        zk = decoding.batch_top_k_top_p_sampling(z, top_k=top_k, top_p=0.0)
+        z_ref = decoding.batch_top_k_top_p_sampling(z, top_k=top_k, top_p=top_p)          # the reference's rule (sort + shifted cumsum)
+        if 0.0 < top_p < 1.0:
+            z_val, above = _top_p_by_value(zk, top_p)
+            clear = ((above - top_p).abs() > 1e-6) | torch.isinf(zk)                        # rows whose boundary is not a rounding matter
+            rows = clear.all(-1)
+            assert rows.sum().item() >= Bn - 1, case
+            assert torch.equal(torch.isinf(z_ref[rows]), torch.isinf(z_val[rows])), case    # by-value rule == reference rule (no ties)
+        else:
+            z_val = z_ref
+        assert ((got >= 0) & (got < V)).all()
+        _assert_draws(got, z_val, u, (case, top_k, top_p))
+        if top_k > 0:
+            assert (~torch.isinf(z_val)).sum(-1).max().item() <= min(top_k, V), case       # (no ties in fp32 noise: exactly <= k survive)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_sampling_kernel_top_p_keeps_equal_logits_together(dtype):
+    """Logits with many exact ties (bf16 logits, quantised fp32): the kernel's kept set is the by-value rule's -- equal logits stay
+    or go together (documented in include/gstvd_hip.h; the reference leaves the order inside a tie to torch.sort) -- and it always
+    contains the reference rule's first kept token (the arg-max)."""
+    from gst_visdial_amd import decoding, ops
+    Bn, V = 10, 30522
+    g = torch.Generator().manual_seed(7)
+    for case, (top_k, top_p) in enumerate([(0, 0.9), (0, 0.3), (100, 0.7), (7, 0.5)]):
+        logits = (torch.randn(Bn, V, generator=g) * 2.0)
+        logits = ((logits * 8).round() / 8).to(DEV).to(dtype)                              # 1/8 steps: thousands of ties per row
+        logits[3, :] = logits[3, 0]                                                        # a constant row
+        u = torch.rand(Bn, generator=g).clamp_min(1e-6).to(DEV)
+        got = torch.full((Bn,), -1, dtype=torch.long, device=DEV)
+        ops.sample_topk(logits, 0.9, top_k, u, got, None, top_p=top_p)
+        z = logits.float() / 0.9
+        zk = decoding.batch_top_k_top_p_sampling(z, top_k=top_k, top_p=0.0)
+        z_val, above = _top_p_by_value(zk, top_p)
+        clear = ((above - top_p).abs() > 1e-6) | torch.isinf(zk)
+        rows = clear.all(-1)
+        assert rows.sum().item() >= Bn - 2, case
+        sel = rows.nonzero().view(-1)
+        _assert_draws(got[sel], z_val[sel], u[sel], (case, top_k, top_p))
+        assert (~torch.isinf(z_val.gather(1, z.argmax(-1, keepdim=True)))).all()
