@@ -222,8 +222,11 @@ def _splitk_scratch(device):
     return ws
 
 
-GROUP_ORDER = int(os.environ.get("GSTVD_GROUP_ORDER", "1"))       # 0: the library's own chunked order (rounds 1-4); 1 / 2: xcd_block_map
+# 0: the library's own chunked order (rounds 1-4); 1: per-XCD queues of whole units; 2: + staggered lead-in; 3 (default): the queues
+# in ROUNDS of an XCD's 32 CUs with short-K fillers; 4: rounds with 30-tile pieces (xcd_block_map)
+GROUP_ORDER = int(os.environ.get("GSTVD_GROUP_ORDER", "3"))
 N_XCD = 8
+XCD_CUS = 32                                # CUs of one XCD = workgroups of the 139 KB-LDS grouped kernels it runs at a time
 GROUP_ORDER_MIN_TILES = 4 * N_XCD * 32      # a few rounds of the chip at least: below that the order is moot (tests lower it)
 
 
@@ -244,14 +247,22 @@ def xcd_block_map(shapes, tile, fused_epilogue, mode=1, unit_tiles=40):
     HBM-bound AdamW epilogues (fused launch) run under the other XCDs' MFMA-bound K-loops instead of all at once.
     `shapes`: [(M, N, K)] per problem in table order; tile ids follow tile_off (problem after problem)."""
     T = tile
+    rounds = mode in (3, 4)
+    if mode == 3:
+        unit_tiles = min(unit_tiles, XCD_CUS - 5)    # 27: a unit must fit one round of an XCD's CUs with room for a few fillers
+    if mode == 4:
+        unit_tiles = XCD_CUS - 2                     # 30: large problems are cut into pieces of 30 tiles + a remainder (36 = 30 + 6)
     units = []                                   # (K, first tile id, number of tiles)
     gid = 0
     for (M, N, K) in shapes:
         nt = ((M + T - 1) // T) * ((N + T - 1) // T)
-        parts = max(1, (nt + unit_tiles - 1) // unit_tiles)
-        base, extra, t0 = nt // parts, nt % parts, gid
-        for i in range(parts):
-            n = base + (1 if i < extra else 0)
+        if mode == 4:
+            sizes = [unit_tiles] * (nt // unit_tiles) + ([nt % unit_tiles] if nt % unit_tiles else [])
+        else:
+            parts = max(1, (nt + unit_tiles - 1) // unit_tiles)
+            sizes = [nt // parts + (1 if i < nt % parts else 0) for i in range(parts)]
+        t0 = gid
+        for n in sizes:
             units.append((K, t0, n))
             t0 += n
         gid += nt
@@ -282,8 +293,35 @@ def xcd_block_map(shapes, tile, fused_epilogue, mode=1, unit_tiles=40):
                 lead.append(u)
                 got += cost(u[0], u[2]) / 32.0   # ~32 tiles of an XCD run at a time
         q = []
-        for (_, t0, n) in lead + ql[x] + qs[x]:
-            q.extend(range(t0, t0 + n))
+        if rounds and ql[x]:
+            # ROUNDS (round 5, second half): an XCD runs XCD_CUS = 32 of these workgroups at a time (139 KB of LDS: one per CU), and
+            # equal-K tiles that start together finish together.  With the long units simply back to back, the window of 32 running
+            # tiles slides across unit boundaries: the first few tiles of a 27- or 36-tile unit run a round earlier than the rest and
+            # stream their operand panels alone.  Here the long units are packed into rounds of <= 32 tiles (first fit, largest
+            # first), and the CUs a round leaves over are kept busy with SHORT-K tiles -- as many as fit into a long tile's time --
+            # so that the next round's long tiles find all their CUs free at the same moment.
+            shorts = [t for (_, t0, n) in qs[x] for t in range(t0, t0 + n)]
+            t_long = cost(ql[x][0][0], 1)
+            t_short = cost(qs[x][0][0], 1) if qs[x] else t_long
+            per_slot = max(1, int(t_long / t_short))
+            bins = []
+            for u in sorted(ql[x], key=lambda u: (-u[2], -u[0], u[1])):
+                for b in bins:
+                    if b[0] + u[2] <= XCD_CUS:
+                        b[0] += u[2]; b[1].append(u); break
+                else:
+                    bins.append([u[2], [u]])
+            si = 0
+            for nl, us in bins:
+                for (_, t0, n) in us:
+                    q.extend(range(t0, t0 + n))
+                nf = min((XCD_CUS - nl) * per_slot, len(shorts) - si)
+                q.extend(shorts[si:si + nf])
+                si += nf
+            q.extend(shorts[si:])
+        else:
+            for (_, t0, n) in lead + ql[x] + qs[x]:
+                q.extend(range(t0, t0 + n))
         queues.append(q)
     depth = max(len(q) for q in queues)
     out = [-1] * (depth * N_XCD)

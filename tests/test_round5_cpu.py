@@ -171,3 +171,47 @@ def test_documented_abi_version_is_the_librarys():
     hdr = hdr.split("#ifdef GSTVD_DIAG")[0]
     declared = set(re.findall(r"\b(gstvd_[a-z0-9_]+)\s*\(", hdr)) - {"gstvd_stream_t"}
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+
+
+@pytest.mark.parametrize("mode", [3, 4])
+def test_xcd_block_map_rounds_keep_whole_long_units_inside_one_round_of_32(mode):
+    """GSTVD_GROUP_ORDER 3 / 4: an XCD's queue is a sequence of ROUNDS -- whole long-K units that together fit its 32 CUs, then
+    short-K fillers for the CUs left over -- so that the tiles of a unit start together; still a placement of every tile exactly
+    once, a small problem never split over XCDs, the queues balanced."""
+    from gst_visdial_amd.ops import xcd_block_map, N_XCD, XCD_CUS
+    shapes = _step_table()
+    T = 256
+    per = [((M + T - 1) // T) * ((N + T - 1) // T) for M, N, K in shapes]
+    total = sum(per)
+    bm = xcd_block_map(shapes, T, True, mode)
+    assert len(bm) % N_XCD == 0 and sorted(t for t in bm if t >= 0) == list(range(total))
+    owner, kk = [], []
+    for i, n in enumerate(per):
+        owner += [i] * n
+        kk += [shapes[i][2]] * n
+    kmax = max(kk)
+    nrounds = []
+    for x in range(N_XCD):
+        q = [t for t in bm[x::N_XCD] if t >= 0]
+        runs, start = [], 0                                          # maximal runs of long-K tiles
+        for j in range(1, len(q) + 1):
+            if j == len(q) or (2 * kk[q[j]] > kmax) != (2 * kk[q[j - 1]] > kmax):
+                runs.append(q[start:j]); start = j
+        long_runs = [r for r in runs if 2 * kk[r[0]] > kmax]
+        assert all(len(r) <= XCD_CUS for r in long_runs)              # a round's long tiles fit the XCD's CUs
+        assert 2 * kk[q[0]] > kmax                                    # the launch starts with a round, not with fillers
+        # a long problem's tiles on this XCD sit in at most ceil(n / 27) rounds, each piece a run of consecutive ids
+        for r in long_runs:
+            ids = sorted(r)
+            pieces = sum(1 for a, b in zip(ids, ids[1:]) if b != a + 1) + 1
+            assert pieces <= len(set(owner[t] for t in r)) + 1
+        for i in set(owner[t] for t in q):
+            if per[i] <= 27:
+                assert sum(1 for t in q if owner[t] == i) == per[i]   # never split over XCDs
+        nrounds.append(len(long_runs))
+    assert max(nrounds) - min(nrounds) <= 3
+
+    def cost(t):
+        return 35.0 + 0.76 * ((kk[t] + 31) // 32)
+    loads = [sum(cost(t) for t in bm[x::N_XCD] if t >= 0) for x in range(N_XCD)]
+    assert max(loads) / min(loads) < 1.03
