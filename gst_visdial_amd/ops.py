@@ -448,7 +448,11 @@ class GemmGroup(object):
             off = torch.tensor(offs, dtype=torch.int32).to(self.device)
             bmap = None
             if GROUP_ORDER and tiles >= GROUP_ORDER_MIN_TILES:
-                bmap = torch.tensor(xcd_block_map([(it[3], it[4], it[5]) for it in key], T, fuse is not None, GROUP_ORDER),
+                # (rounds with fillers pay in the FUSED launch, whose tiles carry 50 us epilogues and which runs near the fabric's
+                # rate: 13.50 -> 13.15 GB, -2.6 %; the plain launch of the N > 1 path is not bound by bytes and fetches less with
+                # whole 36-tile units: 3.44 vs 3.86 GB stand-alone, profiles/r05_group_rounds_ab.txt)
+                mode = 1 if (GROUP_ORDER == 3 and fuse is None) else GROUP_ORDER
+                bmap = torch.tensor(xcd_block_map([(it[3], it[4], it[5]) for it in key], T, fuse is not None, mode),
                                     dtype=torch.int32).to(self.device)
             hit = (tab, off, len(key), tiles, flops, nbytes, bmap)
             if len(self.cache) > 64:
