@@ -773,9 +773,9 @@ __global__ __launch_bounds__(768) void gemm_pc256_nt64_kernel(GemmP p, int ntn, 
 //     panels and run for the same time -- back to back into ONE queue, so that the ~32 tiles an XCD runs at a time stream the
 //     same few panels through its L2 in step.
 //   bmap == nullptr: XCD x walks chunks x, x+8, x+16, ... of 2^chs consecutive tiles (rounds 1-4).
-// A map entry may carry a START BARRIER in its high bits (round 5; ops.xcd_block_map(sync=True)): bits 21-25 = position of the tile
-// inside its unit (a run of consecutive tile ids on one XCD), bits 26-30 = the unit's size - 1 (0: no barrier).  The workgroups of a
-// unit then wait for each other before their K loops (grouped_unit_barrier) so that they walk their shared operand panels in step.
+// A map entry's tile id is its bits 0-20; the bits above are ignored (reserved).  (Round 5 tried a START BARRIER in them -- position of
+// the tile in its unit and the unit's size, the workgroups of a unit waiting for each other before their K loops: 7.5 % fewer operand
+// fetches, 2.3 % slower, and the call cost the fused kernel 256 B/lane of scratch; removed, profiles/r05_group_sync_ab.txt.)
 constexpr int GROUP_TILE_MASK = 0x1fffff;
 DEVFN int grouped_tile_id(const int* bmap, int total, int chs) {
   const int bid = blockIdx.x;
@@ -790,7 +790,7 @@ __global__ __launch_bounds__(512) void gemm_dma256_grouped_kernel(const gstvd_ge
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int entry = grouped_tile_id(bmap, total, chs);
   if (entry < 0) return;
-  const int gid = entry & GROUP_TILE_MASK;      // (start barriers are the fused launch's: see grouped_unit_barrier)
+  const int gid = entry & GROUP_TILE_MASK;
   int lo = 0, hi = nprob - 1;
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tile_off[mid] <= gid) lo = mid; else hi = mid - 1; }
   const gstvd_gemm_t& g = tab[lo];
@@ -922,7 +922,7 @@ __global__ __launch_bounds__(768) void gemm_pc256_grouped_kernel(const gstvd_gem
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int entry = grouped_tile_id(bmap, total, chs);
   if (entry < 0) return;
-  const int gid = entry & GROUP_TILE_MASK;      // (start barriers are the fused launch's: see grouped_unit_barrier)
+  const int gid = entry & GROUP_TILE_MASK;
   int lo = 0, hi = nprob - 1;
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tile_off[mid] <= gid) lo = mid; else hi = mid - 1; }
   const gstvd_gemm_t& g = tab[lo];
@@ -937,31 +937,12 @@ __global__ __launch_bounds__(768) void gemm_pc256_grouped_kernel(const gstvd_gem
   pc_tile256<OT, AKM, BKM, 4, true>(p, 0, gid - tile_off[lo], ntn, ntm * ntn, smem);
 }
 
-// arrive / depart counters of the start barriers, keyed by a unit's first tile id; every workgroup of a unit adds one to each, the last
-// one to depart zeroes both (ready for the next launch).  A wait is bounded (~0.5 ms): a unit whose workgroups are not all resident
-// -- another kernel on the XCD's CUs, a map the host built for another chip -- costs time, never a hang.
-constexpr int UNIT_SYNC_SLOTS = 16384;
-static __device__ int g_unit_sync[2 * UNIT_SYNC_SLOTS];
-DEVFN void grouped_unit_barrier(int first_tile, int size) {
-  if (threadIdx.x == 0 && first_tile < UNIT_SYNC_SLOTS) {
-    int* c = g_unit_sync + 2 * first_tile;
-    __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int spins = 0; spins < 2500 && __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < size; ++spins) __builtin_amdgcn_s_sleep(8);
-    if (__hip_atomic_fetch_add(c + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == size - 1) {
-      __hip_atomic_store(c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(c + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  __syncthreads();
-}
-
 __global__ __launch_bounds__(768) void gemm_pc256_grouped_adamw_kernel(const gstvd_gemm_t* tab, const int* tile_off, int nprob, int total, int chs,
                                                                        const int* bmap, gstvd_adamw_fuse_t af) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int entry = grouped_tile_id(bmap, total, chs);
   if (entry < 0) return;
-  const int gid = entry & GROUP_TILE_MASK, usz = ((entry >> 26) & 31) + 1;
-  if (usz > 1) grouped_unit_barrier(gid - ((entry >> 21) & 31), usz);
+  const int gid = entry & GROUP_TILE_MASK;
   int lo = 0, hi = nprob - 1;
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tile_off[mid] <= gid) lo = mid; else hi = mid - 1; }
   const gstvd_gemm_t& g = tab[lo];

@@ -230,10 +230,7 @@ XCD_CUS = 32                                # CUs of one XCD = workgroups of the
 GROUP_ORDER_MIN_TILES = 4 * N_XCD * 32      # a few rounds of the chip at least: below that the order is moot (tests lower it)
 
 
-GROUP_SYNC = int(os.environ.get("GSTVD_GROUP_SYNC", "0"))       # 1: start barrier between the tiles of a long-K unit (mode 3, fused launch)
-
-
-def xcd_block_map(shapes, tile, fused_epilogue, mode=1, unit_tiles=40, sync=False):
+def xcd_block_map(shapes, tile, fused_epilogue, mode=1, unit_tiles=40):
     """Placement of a grouped launch's tiles (gstvd_gemm_grouped*'s block_map_dev): -> list of tile ids, one per workgroup, -1 =
     idle; entries b, b + 8, b + 16, ... are the queue of ONE XCD (workgroups are dealt to the eight XCDs round-robin).
 
@@ -317,11 +314,7 @@ def xcd_block_map(shapes, tile, fused_epilogue, mode=1, unit_tiles=40, sync=Fals
             si = 0
             for nl, us in bins:
                 for (_, t0, n) in us:
-                    if sync and 1 < n <= 32 and t0 + n < (1 << 21):
-                        # start barrier: position in the unit (bits 21-25) and size - 1 (bits 26-30), csrc/gemm_dma256.hip
-                        q.extend((t0 + j) | (j << 21) | ((n - 1) << 26) for j in range(n))
-                    else:
-                        q.extend(range(t0, t0 + n))
+                    q.extend(range(t0, t0 + n))
                 nf = min((XCD_CUS - nl) * per_slot, len(shorts) - si)
                 q.extend(shorts[si:si + nf])
                 si += nf
@@ -459,8 +452,7 @@ class GemmGroup(object):
                 # rate: 13.50 -> 13.15 GB, -2.6 %; the plain launch of the N > 1 path is not bound by bytes and fetches less with
                 # whole 36-tile units: 3.44 vs 3.86 GB stand-alone, profiles/r05_group_rounds_ab.txt)
                 mode = 1 if (GROUP_ORDER == 3 and fuse is None) else GROUP_ORDER
-                bmap = torch.tensor(xcd_block_map([(it[3], it[4], it[5]) for it in key], T, fuse is not None, mode,
-                                                  sync=bool(GROUP_SYNC and fuse is not None and mode == 3)),
+                bmap = torch.tensor(xcd_block_map([(it[3], it[4], it[5]) for it in key], T, fuse is not None, mode),
                                     dtype=torch.int32).to(self.device)
             hit = (tab, off, len(key), tiles, flops, nbytes, bmap)
             if len(self.cache) > 64:

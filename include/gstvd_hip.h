@@ -95,11 +95,9 @@ int gstvd_gemm_splitk(const gstvd_gemm_t* g, int32_t splits, void* ws, int64_t w
  * caller that knows which problems share operand panels and run equally long (same K) queues them back to back on one XCD,
  * so that the ~32 tiles an XCD runs at a time stream the same panels in step -- autograd has no counterpart, it is pure
  * placement.
- * ABI 6: an entry's tile id is its bits 0-20.  gstvd_gemm_grouped_adamw also honours an optional START BARRIER in the bits
- * above: bits 21-25 = the tile's position inside its unit (a run of consecutive tile ids queued back to back on one XCD),
- * bits 26-30 = the unit's size - 1 (0 = none; units of at most 32 tiles, total_tiles <= 16384): the workgroups of a unit wait
- * for each other before their K loops (bounded: ~0.5 ms, then they go on).  Measured: 7.5 % fewer fetches, 2.3 % slower
- * (profiles/r05_group_sync_ab.txt) -- the host side leaves it off (GSTVD_GROUP_SYNC=1 turns it on). */
+ * ABI 6: an entry's tile id is its bits 0-20 (total_tiles < 2^21); bits 21-30 of a non-negative entry are reserved and
+ * ignored (round 5 measured a start barrier between the workgroups of a unit in them: fewer fetches, slower launch;
+ * profiles/r05_group_sync_ab.txt). */
 int gstvd_gemm_group_tile(void);
 int gstvd_gemm_grouped(const gstvd_gemm_t* table_dev, const int32_t* tile_off_dev, int64_t nprob, int64_t total_tiles,
                        int32_t dtype_in, int32_t dtype_out, int32_t a_kmajor, int32_t b_kmajor,
