@@ -393,8 +393,10 @@ __global__ __launch_bounds__(256) void colsum_batched_kernel(const gstvd_colsum_
   if (rg == 0 && col < W) {
     a = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
     const int64_t j = col / e.H, c = col % e.H;
-    float* o = e.out[j];
-    if (o) o[c] = e.accumulate[j] ? o[c] + a : a;
+    // (selects, not e.out[j]: a dynamically indexed member put the whole entry on the stack -- 88 B/lane of scratch)
+    float* o = j == 0 ? e.out[0] : (j == 1 ? e.out[1] : e.out[2]);
+    const int acc = j == 0 ? e.accumulate[0] : (j == 1 ? e.accumulate[1] : e.accumulate[2]);
+    if (o) o[c] = acc ? o[c] + a : a;
   }
 }
 

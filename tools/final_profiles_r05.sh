@@ -37,7 +37,7 @@ GSTVD_FORCE_DIST=1 python3 bench.py --steps 10 --warmup 3 --legs on $LEAN 2>/dev
 python3 bench.py --steps 10 --warmup 2 --rows-per-gpu 10 --no-cpu-baseline --no-eval-decode --no-fp32 --no-h2d 2>/dev/null | tail -1 > $out/bench_n1_rows10.json
 tail -4 $out/bench_launch_paths.txt | cut -c1-300; cut -c1-200 $out/bench_force_dist_legs.json
 # 9. whole-step A/B records of the switches that stayed (two interleaved rounds each)
-( bash tools/r04_step_ab.sh GSTVD_GROUP_ORDER 0 1; bash tools/r04_step_ab.sh GSTVD_ATTN_ONEPASS 0 1; bash tools/r04_step_ab.sh GSTVD_GEMM64_NS 8 3
+( bash tools/r04_step_ab.sh GSTVD_GROUP_ORDER 0 1 3; bash tools/r04_step_ab.sh GSTVD_ATTN_ONEPASS 0 1; bash tools/r04_step_ab.sh GSTVD_GEMM64_NS 8 3
   bash tools/r04_step_ab.sh GSTVD_ATTN_KEEP_BITS 0 1; bash tools/r04_step_ab.sh GSTVD_ATTN_BWD_ORDER 1 0; bash tools/r04_step_ab.sh GSTVD_FUSE_UPDATE 0 1 ) > $out/step_ab.txt 2>&1; cat $out/step_ab.txt
 # 10. eval / decode side measurements (decode with and without the questioner's 4-gram ban)
 python3 tools/eval_decode_bench.py > $out/eval_decode.json 2> /dev/null; cat $out/eval_decode.json
