@@ -34,6 +34,9 @@ from .config import encoder_schedule
 from ._lib import GstvdError, EPI_GELU, EPI_DGELU, LN_RESID, LN_EMBED, LN_IMAGE
 
 
+EARLY_WGRAD = int(os.environ.get("GSTVD_EARLY_WGRAD", "1"))     # 0: the final grouped weight-gradient launch waits for the embedding backward (A/B)
+
+
 def _round_up(x, m):
     return (x + m - 1) // m * m
 
@@ -470,12 +473,46 @@ class Engine(object):
         if self.pipe is not None and self.pipe.ready(off):
             self._emit(off)
 
+    def _early_final_wgrads(self):
+        """Single-slice pipeline with the fused update (the N = 1 default): every weight-gradient GEMM of the step is queued once
+        backward reaches the encoder's text embedding -- what is left is that embedding's backward (scatter-adds, 33 us), and the
+        column reductions of the LayerNorm / bias gradients (47 us): inputs of the REMAINDER AdamW pass, not of the grouped
+        launch.  So the grouped launch starts here on the auxiliary stream and those two run beside it instead of in front of it
+        (GSTVD_EARLY_WGRAD=0: the launch waits for them, as in rounds 4-5a)."""
+        p = self.pipe
+        if not self.use_streams or p is None or p.hi is None or p.slices or p.hi != self.flat.n_live or p.fuse_handle() is None:
+            return
+        if any(self.wgrads.pending_into(self.Gv[n]) for n in ("emb.word", "emb.pos", "emb.tt", "emb.tte") if n in self.Gv):
+            return      # a queued GEMM writes a table the embedding's backward is about to add into (tied LM head): keep the order
+        for src in (self.main, self.side):
+            ev = torch.cuda.Event()
+            ev.record(src)
+            self.aux.wait_event(ev)
+        with torch.cuda.stream(self.aux):
+            self._early_fused = self.wgrads.flush(fuse=p.fuse_handle())
+        self._early = True
+        self.aux_busy = True
+
     def _emit(self, off):
         """Hand the finished slice [off, pipe.hi) to the backward pipeline on the auxiliary stream."""
         for src in ([self.main, self.side] if self.use_streams else [self.main]):
             ev = torch.cuda.Event()
             ev.record(src)
             self.aux.wait_event(ev)
+        if off == 0 and self.use_streams and getattr(self, "_early", False):
+            # the grouped launch is already running (see _early_final_wgrads); a GEMM queued after it (none in this model) goes plain
+            self._early = False
+            fused = self._early_fused
+            with torch.cuda.stream(self.aux):
+                self.wgrads.flush()
+            self.colsums.flush()
+            ev = torch.cuda.Event()
+            ev.record(self.main)
+            self.aux.wait_event(ev)
+            with torch.cuda.stream(self.aux):
+                self.pipe.run_slice(off, self.pipe.hi, fused=fused)
+            self.aux_busy = True
+            return
         if off == 0 and self.use_streams:
             # the last slice, after backward's last kernel: the main stream has nothing left to do, so the slice's column
             # reductions run there, beside its grouped weight-gradient launch on the auxiliary stream (which then waits for them).
@@ -820,6 +857,8 @@ class Engine(object):
         c = self.enc_cfg
         Bn, T, R = I["B"], I["T"], I["R"]
         xt = self.embed("emb", I["ids"], I["segs"], Bn, T, c, label="emb.enc")
+        if self.rec and self.pipe is not None and EARLY_WGRAD:
+            self.tape.append(("t", self._early_final_wgrads))       # backward: runs just before this embedding's backward
         f = Act(I["feats"], Bn * R, c.v_feature_size)
         self.sync("v", "t")                   # fork: the vision stream starts once the inputs are staged
         with self.on("v"):
@@ -1024,6 +1063,7 @@ class Engine(object):
                 elif p.grad.data_ptr() != gv.data_ptr():
                     gv.copy_(p.grad)
         self.written = set()
+        self._early = False
         self.colsums.reset()
         self.wgrads.reset()
         logits = st["logits"]
