@@ -1,5 +1,6 @@
 #!/bin/bash
 # Round 5, GPU session 20: start barrier between the workgroups of a long-K unit of the fused weight-gradient launch (GSTVD_GROUP_SYNC):
+# (the start-barrier code this session measured was removed again afterwards -- GSTVD_GROUP_SYNC has no effect on the current tree; see profiles/r05_group_sync_ab.txt)
 # parity tests, step A/B, kernel time, FETCH / WRITE.
 export TMPDIR=/tmp; out=gpurun_out/r05_s20; rm -rf $out; mkdir -p $out
 LEAN="--no-cpu-baseline --no-eval-decode --no-breakdown --no-fp32 --no-h2d"
