@@ -228,6 +228,7 @@ class FlatParams(object):
         self.dead = [p for p in model.parameters() if id(p) not in live_ids]
         self.precision = precision
         self.P = self.G = self.S = self.D = None
+        self.stale_guard = None       # callable -> True while fp32 masters of other ranks' shards are old (set by the engine)
 
     # -- materialise on the device the parameters currently live on ------------------------------------
     def materialize(self, device):
@@ -267,6 +268,14 @@ class FlatParams(object):
             return
         v = self.version()
         if force or v != self.shadow_version:
+            if self.shadow_version is not None and self.stale_guard is not None and self.stale_guard():
+                # sharded optimizer (pipeline.BackwardPipeline(shard_update=True)): P holds current master weights only for this
+                # rank's shards, S holds the freshly GATHERED shadows of all of them -- a re-cast would replace other ranks' current
+                # bf16 weights by this rank's old masters and the ranks would diverge silently
+                from ._lib import GstvdError
+                raise GstvdError("a parameter was modified in place while the optimizer is sharded over the ranks: the bf16 shadow "
+                                 "weights cannot be re-derived from this rank's fp32 masters (current only for its own shards).  "
+                                 "Call pipe.sync_master() on EVERY rank before editing parameters.")
             ops.cast(self.P, self.S)
             self.shadow_version = v
 
@@ -385,6 +394,7 @@ class Engine(object):
         if self.flat is None or self.flat.topo != topo:
             self.flat = FlatParams(self.model, self.precision)
             self.flat.topo = topo
+            self.flat.stale_guard = lambda: self.pipe is not None and bool(getattr(self.pipe, "master_stale", False))
         if self.flat.is_materialized() and self.flat.device != device:
             # the parameters live (as views of the flat buffer) on one device and the inputs arrive on another: a replica of
             # nn.DataParallel(model, [0, 1, ...]) (train_gen.py:295, README.md:89) -- replicas would share this one engine

@@ -265,6 +265,14 @@ class DecoderOutput(object):
         self.past_key_values = self.decoder_hidden_states = self.decoder_attentions = self.cross_attentions = None
 
 
+def _check_master_current(engine, what):
+    """state_dict() of the model OR of one of its sub-modules (train_gen.py:346-357 saves `model.module.encoder` /
+    `.decoder` state dicts separately in some forks): refused while a sharded optimizer holds stale fp32 masters here."""
+    pipe = getattr(engine, "pipe", None) if engine is not None else None
+    if pipe is not None and hasattr(pipe, "check_master_current"):
+        pipe.check_master_current(what)
+
+
 class VisualDialogEncoder(nn.Module):
     """models/visual_dialog_encoder.py:7-76.  `params` is held by reference and re-read on every call."""
 
@@ -283,6 +291,11 @@ class VisualDialogEncoder(nn.Module):
         # load_state_dict / a checkpoint, with BERT-style N(0, 0.02) init as the starting point
         self.bert_pretrained = BertForMultiModalPreTraining(self.config)
         self._engine_owner = None
+
+    def state_dict(self, *args, **kwargs):
+        if not kwargs.get("prefix") and not (len(args) > 1 and args[1]):      # (a parent's state_dict() has checked already)
+            _check_master_current(getattr(self, "_standalone_engine", None), "model.encoder.state_dict()")
+        return super().state_dict(*args, **kwargs)
 
     def forward(self, input_ids, image_feat, image_loc, sep_indices=None, token_type_ids=None, attention_mask=None,
                 masked_lm_labels=None, next_sentence_label=None, image_attention_mask=None, image_label=None,
@@ -303,6 +316,11 @@ class VisualDialogDecoder(nn.Module):
         self.config.__dict__["cur_device"] = params["gpu_ids"][0]
         self.config.validate()
         self.decoder = BertForSequenceGeneration(self.config)
+
+    def state_dict(self, *args, **kwargs):
+        if not kwargs.get("prefix") and not (len(args) > 1 and args[1]):
+            _check_master_current(getattr(self, "_standalone_engine", None), "model.decoder.state_dict()")
+        return super().state_dict(*args, **kwargs)
 
     def _reorder_cache(self, past, beam_idx):
         return self.decoder._reorder_cache(past, beam_idx)
@@ -339,9 +357,7 @@ class EncoderDecoderModel(nn.Module):
         return self._engine
 
     def state_dict(self, *args, **kwargs):
-        eng = self._engine
-        if eng is not None and getattr(eng, "pipe", None) is not None and hasattr(eng.pipe, "check_master_current"):
-            eng.pipe.check_master_current("model.state_dict()")
+        _check_master_current(self._engine, "model.state_dict()")
         return super().state_dict(*args, **kwargs)
 
     def _replicate_for_data_parallel(self):

@@ -43,7 +43,12 @@ class BackwardPipeline(object):
         # time per step), this one 1/N of it, for the same bytes on the links.  See _run_sharded.
         self.shard_update = bool(shard_update)
         self._plans = {}
-        self.master_stale = False     # sharded steps ran since the last sync_master(): fp32 masters / moments of other ranks' shards are old
+        # Staleness of the fp32 masters / moments of the OTHER ranks' shards is derived from DEVICE state, not from a host flag: under
+        # hipGraph replay _run_sharded's host code runs once, at capture, while every replay advances the optimizer's device-resident
+        # step counter.  `_sharded_seen`: a sharded slice with a non-empty bulk has been issued (eagerly or into a capture) at all;
+        # `_synced_step`: the optimizer step count at the last sync_master() (None: never synced).  See the `master_stale` property.
+        self._sharded_seen = False
+        self._synced_step = None
         # compress="bf16": the slice is cast to bf16, all-reduced, and (with an optimizer attached) consumed by AdamW
         # straight from the bf16 copy; the fp32 buffer G / `.grad` then keeps the LOCAL gradients unless keep_grads
         self.keep_grads = keep_grads
@@ -68,6 +73,17 @@ class BackwardPipeline(object):
         self._skip_next = self._skipping = False
         self._stale = set()           # flat offsets of the weights whose gradient the LAST backward never stored (fused update)
         engine.pipe = self
+
+    @property
+    def master_stale(self):
+        """True while sharded optimizer steps have run since the last sync_master(): this rank's fp32 master weights / moments of the
+        other ranks' shards are old.  Compares the optimizer's DEVICE step counter (it advances inside a replayed hipGraph; a host
+        flag set by _run_sharded would not) with its value at the last sync_master().  Reads the counter: not during a capture."""
+        if not (self.shard_update and self.world > 1 and self._sharded_seen and self.opt is not None):
+            return False
+        if self._synced_step is None:
+            return True
+        return self.opt._sync_step() != self._synced_step
 
     def skip_update_once(self):
         """The NEXT backward only produces gradients: no all-reduce, no optimizer step, nothing zeroed -- iteration 0 of
@@ -299,7 +315,7 @@ class BackwardPipeline(object):
             if pl["rest"]:
                 opt.apply_range(lo + bulk, hi)
         if S:
-            self.master_stale = self.world > 1
+            self._sharded_seen = True
             W = flat.S if getattr(flat, "S", None) is not None else flat.P
             dist.all_gather_into_tensor(W[lo:lo + bulk], W[a:b], group=self.group)
             pk = pl["pack"]
@@ -331,7 +347,7 @@ class BackwardPipeline(object):
             a, b, bulk = pl["a"], pl["b"], pl["bulk"]
             for buf in (flat.P, opt.m, opt.v):
                 dist.all_gather_into_tensor(buf[lo:lo + bulk], buf[a:b].clone(), group=self.group)
-        self.master_stale = False
+        self._synced_step = opt._sync_step()      # (device counter: correct after any number of graph replays)
 
     def check_master_current(self, what):
         """state_dict() / checkpoint guard: a COLLECTIVE must not hide inside a call that train_gen.py:346-357 makes on one process

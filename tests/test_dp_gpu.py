@@ -68,7 +68,32 @@ def _worker_body(rank, world, port, q, train, shard=False, prec="fp32"):
         except GstvdError as e:
             stale = "sync_master" in str(e)
         pipe.sync_master()                      # fp32 masters / moments of the other rank's shards: gathered on demand
+        model.state_dict(); opt.state_dict(); model.encoder.state_dict(); model.decoder.state_dict()
+        # what a hipGraph REPLAY of the sharded step does: the device step counter advances, no host code of pipeline.py runs
+        # (the guard was a host flag and stayed clear from here on).  Every state_dict() must refuse again.
+        opt.step_dev.add_(1.0)
+        refused = []
+        for fn in (model.state_dict, opt.state_dict, model.encoder.state_dict, model.decoder.state_dict, opt.export_reference_state):
+            try:
+                fn()
+                refused.append(False)
+            except GstvdError as e:
+                refused.append("sync_master" in str(e))
+        # ... and so must an in-place parameter edit, which would re-cast this rank's stale masters over the gathered shadows
+        if model.engine.flat.S is not None:
+            with torch.no_grad():
+                model.vlfusion.fc_v.weight.mul_(1.0)
+            try:
+                model.engine.flat.refresh_shadow()
+                refused.append(False)
+            except GstvdError as e:
+                refused.append("sync_master" in str(e))
+        opt.step_dev.add_(-1.0)
+        stale = stale and all(refused)
+        pipe.sync_master()
         model.state_dict(); opt.state_dict()
+        if model.engine.flat.S is not None:
+            model.engine.flat.refresh_shadow()  # masters are current: the re-cast is legal again
         torch.cuda.synchronize()
     mask = None
     if train:           # the keep mask this rank's LAST step drew at one site (ranks must not share a mask stream)

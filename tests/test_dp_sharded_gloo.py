@@ -66,6 +66,9 @@ class _HostAdamW:
     def begin_step(self):
         self.t += 1
 
+    def _sync_step(self):          # FusedAdamW: the DEVICE step counter (it advances inside a replayed hipGraph)
+        return self.t
+
     def apply_range(self, lo, hi, grad_bf16=None, fused=(), grad_origin=None):
         f = self.engine.flat
         self.calls.append((lo, hi))
@@ -127,10 +130,22 @@ def _worker(rank, world, port, n, marks, chunk, compress, shadow, steps, q):
         for lo, hi in opt.calls:
             cover[lo:hi] += 1
         stale_before = (f.P != rf.P).float().mean().item() if world > 1 else 0.0
+        flags = [pipe.master_stale]
         pipe.sync_master()
+        flags.append(pipe.master_stale)
+        # a hipGraph REPLAY of a sharded step: the captured kernels advance the optimizer's device step counter, none of
+        # pipeline.py's host code runs (a host flag set in _run_sharded stayed False from here on)
+        opt.t += 1
+        flags.append(pipe.master_stale)
+        try:
+            pipe.check_master_current("state_dict()")
+            flags.append("no error")
+        except Exception as e:      # noqa: BLE001
+            flags.append("sync_master" in str(e))
+        opt.t -= 1
         out = dict(rank=rank, slices=list(pipe.slices), vis=vis.numpy(), ref_vis=ref_vis.numpy(), vis_p=vis_p.numpy(), ref_vis_p=ref_vis_p.numpy(),
                    P=f.P.numpy().copy(), m=opt.m.numpy().copy(), v=opt.v.numpy().copy(), refP=rf.P.numpy().copy(), refm=ref_opt.m.numpy().copy(),
-                   cover=cover.numpy(), stale_before=stale_before, plans={k: (p["S"], p["bulk"], p["rest"], p["a"], p["b"]) for k, p in pipe._plans.items()})
+                   cover=cover.numpy(), stale_before=stale_before, stale_flags=flags, plans={k: (p["S"], p["bulk"], p["rest"], p["a"], p["b"]) for k, p in pipe._plans.items()})
         q.put(out)
         dist.barrier()
         dist.destroy_process_group()
@@ -183,6 +198,8 @@ def test_sharded_update_matches_allreduce_path(world, compress, shadow, slice_mi
     assert (tot[~in_rest] == steps).all() and (tot[in_rest] == steps * world).all()
     assert any(p[0] > 0 for p in r0["plans"].values()) and in_rest.any()
     # --- ranks agree bit for bit on everything the forward reads, and (after sync_master) on master weights and moments
+    for r in res:      # stale before sync_master(), current after it, stale again after a (simulated) graph replay, and the guard raises
+        assert r["stale_flags"] == [True, False, True, True], r["stale_flags"]
     for r in res[1:]:
         assert (r["vis"] == r0["vis"]).all() and (r["vis_p"] == r0["vis_p"]).all()
         assert (r["P"] == r0["P"]).all() and (r["m"] == r0["m"]).all() and (r["v"] == r0["v"]).all()
