@@ -1053,9 +1053,8 @@ template <typename T, int D> static int attn_bwd_launch(const gstvd_attn_t& a, h
   if (rc) return rc;
   const int nkb = (a.Lk + 63) / 64, nqb = (a.Lq + 63) / 64;
   // a dQ block walks nkb key chunks, a dK/dV block nqb query chunks (with two second products per tile: the longer one at a tie);
-  // GSTVD_ATTN_BWD_ORDER=0: the interleaved order of rounds 1-4 is not kept -- 1 forces dK/dV first, 2 dQ first (A/B)
-  static const int order = [] { const char* e = getenv("GSTVD_ATTN_BWD_ORDER"); return e ? atoi(e) : 0; }();
-  const int dq_first = order == 1 ? 0 : order == 2 ? 1 : (nkb > nqb ? 1 : 0);
+  // the longer-running class goes first (round 5, profiles/r05_attn_block_order.txt; the forced orders of that A/B are gone)
+  const int dq_first = nkb > nqb ? 1 : 0;
   dim3 grid((unsigned)((nkb + nqb) * a.nh * a.B));
   hipLaunchKernelGGL((attn_bwd_kernel<T, D>), grid, dim3(256), lds, s, a, nkb, nqb, dq_first);
   GSTVD_LAUNCH_CHECK();

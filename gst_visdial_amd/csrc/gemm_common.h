@@ -139,7 +139,11 @@ DEVFN void st8(bf16* q, const f32x4& lo, const f32x4& hi) {
   *(bf16x8*)q = v;
 }
 
-template <int MI, int NI, int HB>
+// LATE: the addend / aux rows of a pass are fetched AFTER its accumulators are parked instead of in front of them.  The
+// producer / consumer tiles run three waves per SIMD (168 VGPRs): with all 128 accumulator registers of a 256-wide tile still
+// live, 32 registers of prefetched rows spilled ~100 B per lane to scratch; once half of the accumulators
+// sit in LDS there is room.  One load latency per pass is exposed instead (the rows are consumed in issue order).
+template <int MI, int NI, int HB, bool LATE = false>
 DEVFN void gemm_epilogue_rows(const GemmP& p, const DropKey& dk, const f32x4 (&acc)[MI][NI], int64_t z, int64_t mw, int64_t nw,
                               char* lds_wave, int lane) {
   static_assert(MI % HB == 0, "row blocks per pass must divide the wave tile");
@@ -162,64 +166,76 @@ DEVFN void gemm_epilogue_rows(const GemmP& p, const DropKey& dk, const f32x4 (&a
   const bool pre_add = (p.epi & GSTVD_EPI_ADD) != 0, pre_aux = !pre_add && (p.epi & GSTVD_EPI_DGELU);
   const bf16* pre_base = pre_add ? (const bf16*)p.addend + z * p.sAdd : (const bf16*)p.aux + z * p.sAux;
   const int64_t pre_ld = pre_add ? p.ldadd : p.ldaux;
+  // LATE: two sub-batches of row groups per pass, each fetched right in front of its use (16 instead of 32 registers of rows)
+  constexpr int NR = ROWS / RPI, SUBN = (LATE && NR % 2 == 0) ? 2 : 1, NRS = NR / SUBN;
 #pragma unroll
   for (int pb = 0; pb < MI / HB; ++pb) {
-    bf16x8 pre[ROWS / RPI];
-    if (pre_add || pre_aux) {
+    bf16x8 pre[NRS];
+    auto fetch_pre = [&](int sb) {
+      if (pre_add || pre_aux) {
 #pragma unroll
-      for (int rr = 0; rr < ROWS / RPI; ++rr) {
-        const int64_t m = mw + pb * ROWS + rr * RPI + rl;
-        typedef __attribute__((ext_vector_type(8))) short s16x8;
-        const s16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-        pre[rr] = __builtin_bit_cast(bf16x8, zero);
-        if (m < p.M && n_hi) pre[rr] = *(const bf16x8*)(pre_base + m * pre_ld + n);
-        else if (m < p.M && n_lo) {
-          const bf16x4 h = *(const bf16x4*)(pre_base + m * pre_ld + n);
-          pre[rr][0] = h[0]; pre[rr][1] = h[1]; pre[rr][2] = h[2]; pre[rr][3] = h[3];
+        for (int rr = 0; rr < NRS; ++rr) {
+          const int64_t m = mw + pb * ROWS + (sb * NRS + rr) * RPI + rl;
+          typedef __attribute__((ext_vector_type(8))) short s16x8;
+          const s16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+          pre[rr] = __builtin_bit_cast(bf16x8, zero);
+          if (m < p.M && n_hi) pre[rr] = *(const bf16x8*)(pre_base + m * pre_ld + n);
+          else if (m < p.M && n_lo) {
+            const bf16x4 h = *(const bf16x4*)(pre_base + m * pre_ld + n);
+            pre[rr][0] = h[0]; pre[rr][1] = h[1]; pre[rr][2] = h[2]; pre[rr][3] = h[3];
+          }
         }
       }
-    }
+    };
+    if (!LATE) fetch_pre(0);
 #pragma unroll
     for (int i = 0; i < HB; ++i)
 #pragma unroll
       for (int j = 0; j < NI; ++j) *(f32x4*)(park + (i * 16 + li) * S + j * 16 + 4 * g) = acc[pb * HB + i][j];
 #pragma unroll
-    for (int rr = 0; rr < ROWS / RPI; ++rr) {
-      const int row = rr * RPI + rl;
-      const int64_t m = mw + pb * ROWS + row;
-      if (m >= p.M || !n_lo) continue;
-      f32x4 lo = *(const f32x4*)(park + row * S + c8), hi = *(const f32x4*)(park + row * S + c8 + 4);
-      lo = lo * p.alpha + b_lo;
-      hi = hi * p.alpha + b_hi;
-      const bool full = n_hi;
-      const f32x4 q_lo = {(float)pre[rr][0], (float)pre[rr][1], (float)pre[rr][2], (float)pre[rr][3]};
-      const f32x4 q_hi = {(float)pre[rr][4], (float)pre[rr][5], (float)pre[rr][6], (float)pre[rr][7]};
-      if (pre_add) { lo += q_lo; hi += q_hi; }
-      if (p.epi & GSTVD_EPI_GELU) {
-        f32x4 d0, d1;
+    for (int sb = 0; sb < SUBN; ++sb) {
+      if (LATE) {
+        __builtin_amdgcn_sched_barrier(0);      // the parking stores / the previous sub-batch are issued before these loads
+        fetch_pre(sb);
+      }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float g_, d_;
-          gelu_both<true>(lo[e], g_, d_); lo[e] = g_; d0[e] = d_;
-          gelu_both<true>(hi[e], g_, d_); hi[e] = g_; d1[e] = d_;
+      for (int rr = 0; rr < NRS; ++rr) {
+        const int row = (sb * NRS + rr) * RPI + rl;
+        const int64_t m = mw + pb * ROWS + row;
+        if (m >= p.M || !n_lo) continue;
+        f32x4 lo = *(const f32x4*)(park + row * S + c8), hi = *(const f32x4*)(park + row * S + c8 + 4);
+        lo = lo * p.alpha + b_lo;
+        hi = hi * p.alpha + b_hi;
+        const bool full = n_hi;
+        const f32x4 q_lo = {(float)pre[rr][0], (float)pre[rr][1], (float)pre[rr][2], (float)pre[rr][3]};
+        const f32x4 q_hi = {(float)pre[rr][4], (float)pre[rr][5], (float)pre[rr][6], (float)pre[rr][7]};
+        if (pre_add) { lo += q_lo; hi += q_hi; }
+        if (p.epi & GSTVD_EPI_GELU) {
+          f32x4 d0, d1;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float g_, d_;
+            gelu_both<true>(lo[e], g_, d_); lo[e] = g_; d0[e] = d_;
+            gelu_both<true>(hi[e], g_, d_); hi[e] = g_; d1[e] = d_;
+          }
+          bf16* xp = (bf16*)p.aux + z * p.sAux + m * p.ldaux + n;
+          if (full) st8(xp, d0, d1); else st4(xp, d0);
         }
-        bf16* xp = (bf16*)p.aux + z * p.sAux + m * p.ldaux + n;
-        if (full) st8(xp, d0, d1); else st4(xp, d0);
-      }
-      if (p.epi & GSTVD_EPI_DGELU) {
-        if (pre_aux) { lo *= q_lo; hi *= q_hi; }
-        else {
-          const bf16* xp = (const bf16*)p.aux + z * p.sAux + m * p.ldaux + n;
-          if (full) { f32x4 a0, a1; ld8(xp, a0, a1); lo *= a0; hi *= a1; }
-          else lo *= ld4(xp);
+        if (p.epi & GSTVD_EPI_DGELU) {
+          if (pre_aux) { lo *= q_lo; hi *= q_hi; }
+          else {
+            const bf16* xp = (const bf16*)p.aux + z * p.sAux + m * p.ldaux + n;
+            if (full) { f32x4 a0, a1; ld8(xp, a0, a1); lo *= a0; hi *= a1; }
+            else lo *= ld4(xp);
+          }
         }
+        if (dk.on) {
+          const uint64_t e0 = (uint64_t)((z * p.M + m) * p.N + n);
+          lo *= drop_factor4(dk, e0);
+          if (full) hi *= drop_factor4(dk, e0 + 4);
+        }
+        if (full) st8(C + m * p.ldc + n, lo, hi); else st4(C + m * p.ldc + n, lo);
       }
-      if (dk.on) {
-        const uint64_t e0 = (uint64_t)((z * p.M + m) * p.N + n);
-        lo *= drop_factor4(dk, e0);
-        if (full) hi *= drop_factor4(dk, e0 + 4);
-      }
-      if (full) st8(C + m * p.ldc + n, lo, hi); else st4(C + m * p.ldc + n, lo);
     }
   }
 }

@@ -221,31 +221,19 @@ static int dma_launch(const GemmP& p, int64_t batch, hipStream_t s) {
 
 template <typename OT, bool AKM, bool BKM>
 static int dma_layout(const GemmP& p, int64_t batch, hipStream_t s) {
-  // GSTVD_GEMM_VARIANT (read once) selects a main-loop variant for tuning runs: 0 = default policy,
-  // 1 = always the register-staged kernel of gemm.hip, 2 = 4-wave 128x128 ring, 3 = 64x64 ring with 6 stages
-  static const int variant = [] { const char* e = getenv("GSTVD_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
-  if (variant == 1) return GSTVD_E_UNSUPPORTED;
   const int64_t big = ((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
   if (p.M >= 256 && p.N >= 128 && big >= 96) {
-    if (variant == 2) return dma_launch<OT, 128, 128, 2, 4, AKM, BKM, 4>(p, batch, s);
     // 96-wide tiles when they turn a partially filled round of CUs into a full one (N = 768: 192 -> 256 tiles)
-    static const int n96 = [] { const char* e = getenv("GSTVD_GEMM128_N96"); return e ? atoi(e) : 1; }();
     const int64_t ntm = (p.M + 127) / 128, t128 = ntm * ((p.N + 127) / 128) * batch, t96 = ntm * ((p.N + 95) / 96) * batch;
     const double nkt = (double)((p.K + 63) / 64);
     const double c128 = (double)((t128 + 255) / 256) * (8.0 + 0.45 * nkt), c96 = (double)((t96 + 255) / 256) * (8.0 + 0.40 * nkt);
     // Ring depth 3 (96 KB), not 5 (160 KB = the whole LDS of a CU): the K-step rate is the same (0.52-0.65 against
     // 0.56-0.62 us per 64-deep step -- the loop is bound by the L2 -> LDS feed rate, not by the bytes in flight), and the
     // 64 KB left free let a workgroup of another stream's kernel share the CU: 1174-1178 against 1167-1172 rounds/s in
-    // the step (round 3).  GSTVD_GEMM128_NS=5 keeps the deep ring for A/B.
-    static const int ns128 = [] { const char* e = getenv("GSTVD_GEMM128_NS"); return e ? atoi(e) : 3; }();
-    if (n96 == 2 || (n96 == 1 && c96 < c128)) {
-      if (ns128 == 5) return dma_launch<OT, 128, 128, 4, 2, AKM, BKM, 5, 3>(p, batch, s);
-      return dma_launch<OT, 128, 128, 4, 2, AKM, BKM, 3, 3>(p, batch, s);
-    }
-    if (ns128 == 5) return dma_launch<OT, 128, 128, 2, 4, AKM, BKM, 5>(p, batch, s);
+    // the step (round 3).
+    if (c96 < c128) return dma_launch<OT, 128, 128, 4, 2, AKM, BKM, 3, 3>(p, batch, s);
     return dma_launch<OT, 128, 128, 2, 4, AKM, BKM, 3>(p, batch, s);
   }
-  if (variant == 3) return dma_launch<OT, 64, 64, 2, 2, AKM, BKM, 4>(p, batch, s);
   // (32x32 / 32x64 tiles for the skinny M = 400 / 592 problems were measured in round 2: no faster -- 400x768x768 9.8-11.0 us
   // against 10.2 us, 592x1024x1024 16.5 us against 13.1 us -- the ring of a workgroup is latency bound, 7 stages x stage
   // bytes in flight per ~2 us round trip, so halving the tile halves the bytes in flight along with the bytes needed.
@@ -256,10 +244,7 @@ static int dma_layout(const GemmP& p, int64_t batch, hipStream_t s) {
   // 128 KB workgroup of the vision / decoder chains could only start on a CU that a text-chain workgroup (96 KB, 128-tile kernels)
   // had just left -- 8.6-11.9 us alone against 25.8-33.8 us whenever a text kernel was in flight (profiles/r04_overlap_stats.txt);
   // with 48 KB it fits beside one: whole step 12.40 / 12.45 (8 stages) vs 12.37 / 12.37 (4) vs 12.23 / 12.24 ms (3),
-  // profiles/r05_gemm64_ns_ab.txt.  GSTVD_GEMM64_NS=8 / 4 restore the deeper rings for A/B runs.
-  static const int ns64 = [] { const char* e = getenv("GSTVD_GEMM64_NS"); return e ? atoi(e) : 3; }();
-  if (ns64 == 8) return dma_launch<OT, 64, 64, 2, 2, AKM, BKM, 8>(p, batch, s);
-  if (ns64 == 4) return dma_launch<OT, 64, 64, 2, 2, AKM, BKM, 4>(p, batch, s);
+  // profiles/r05_gemm64_ns_ab.txt.
   return dma_launch<OT, 64, 64, 2, 2, AKM, BKM, 3>(p, batch, s);
 }
 
@@ -278,9 +263,7 @@ static int splitk_launch_ns(const GemmP& p, int S, void* ws, int64_t ws_bytes, h
 
 template <typename OT, bool AKM, bool BKM>
 static int splitk_launch(const GemmP& p, int S, void* ws, int64_t ws_bytes, hipStream_t s) {
-  // ring depth of the split-K form: 8 (rounds 2-4) or, GSTVD_GEMM64_SK_NS=4, four stages / 64 KB (A/B)
-  static const int ns = [] { const char* e = getenv("GSTVD_GEMM64_SK_NS"); return e ? atoi(e) : 8; }();
-  if (ns == 4) return splitk_launch_ns<OT, AKM, BKM, 4>(p, S, ws, ws_bytes, s);
+  // ring depth of the split-K form: 8 (four stages / 64 KB measured no better inside the step, profiles/r05_gemm64_sk_ns_ab.txt)
   return splitk_launch_ns<OT, AKM, BKM, 8>(p, S, ws, ws_bytes, s);
 }
 

@@ -35,6 +35,7 @@ constexpr bool kDiag = false;
 #endif
 
 
+DEVFN int opaque_lane(int lane) { asm volatile("" : "+v"(lane)); return lane; }
 DEVFN int rm32_off(int row, int slot) { return row * 64 + ((slot ^ (((row >> 3) & 1) << 1)) << 4); }
 template <int BX> DEVFN int km32_off(int krow, int col) {
   constexpr int NB = BX / 16;
@@ -98,7 +99,7 @@ struct Dma32 {
 // NIU = 16-column accumulator tiles per wave actually used (4: the full 256-wide tile; 3: a 192-wide tile inside the same
 // 256-wide LDS image -- N = 3072 then gives 16 x 16 = 256 tiles, one per CU, instead of 192 tiles on 256 CUs).
 // ST = K-step schedule: 0 the compiler's own order (DMA issue, then fragment reads two A fragments at a time in front of the
-// MFMAs that use them); 4 all twelve fragment reads first, then the DMA issue under their latency (GSTVD_GEMM_ST=4; correct
+// MFMAs that use them); 4 all twelve fragment reads first, then the DMA issue under their latency (diagnostic build, GSTVD_DIAG_ST=4; correct
 // results, measured -4 % per step in isolation, nothing inside the step).  Staggered-issue schedules (round 2's ST = 1 / 2 / 5)
 // measured no gain and are gone (profiles/r02_gemm_kloop_study.txt).
 // PF < 0 (except -5, the ping-pong tile) and ST = 3 are timing-only ablations of the diagnostic build (kDiag).
@@ -138,7 +139,7 @@ DEVFN void dma_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char
     ub.issue(s, p.K, smem + s * STAGE + A_BYTES, wave);
   }
   int slot = 0, fill = NS - 1;
-  static_assert(kDiag || ((PF == 0 || PF == -5) && (ST == 0 || ST == 4)), "timing ablations belong to the -DGSTVD_DIAG build");
+  static_assert(kDiag || (PF == 0 && ST == 0), "schedule variants and timing ablations belong to the -DGSTVD_DIAG build");
 #ifdef GSTVD_DIAG
   unsigned long long clk0 = 0, rt0 = 0;
   if (ST == 3) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
@@ -407,7 +408,7 @@ DEVFN void adamw_rows_pass(const gstvd_adamw_fuse_t& af, float alpha, float lr, 
   }
 }
 
-// Producer / consumer form of the same tile (GSTVD_GEMM_PC=1): 12 waves.  Waves 0-7 are the MFMA consumers of dma_tile256 (128x64 each)
+// Producer / consumer form of the same tile (the default; GSTVD_GEMM_PC=0 switches it off): 12 waves.  Waves 0-7 are the MFMA consumers of dma_tile256 (128x64 each)
 // and never touch the memory pipeline; waves 8-11 are LDS-DMA producers (8 pieces of 1 KB per wave and stage) and never touch
 // the matrix pipe.  One s_barrier per K-step still orders everything: before barrier t every producer has waited for its pieces
 // of stage t (counted vmcnt) and every consumer has retired its fragment reads of slot t-1, so after it the consumers read slot t
@@ -560,7 +561,11 @@ DEVFN void pc_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char*
     slot = (slot + 1 == NS) ? 0 : slot + 1;
   }
   __builtin_amdgcn_s_barrier();       // every producer has drained its DMAs, every consumer is done with the ring: LDS is free
-  const int g = lane >> 4, li = lane & 15;
+  // The epilogue's per-lane addresses are derived from an OPAQUE copy of the lane id: derived from `lane` the compiler computes
+  // them in front of the K loop and, at the 168-VGPR cap of three waves per SIMD, spills them across it (8-28 B of scratch per
+  // lane, which also makes the dispatch set up scratch memory) -- VERDICT r5 item 1b.
+  const int lane_e = (sizeof(OT) == 4 || ADAM) ? opaque_lane(lane) : lane;     // (the row-wise bf16 epilogue is better off without it)
+  const int g = lane_e >> 4, li = lane_e & 15;
   if constexpr (ADAM) {
     if (p.epi & GSTVD_EPI_ADAMW) {
       // park 64 rows, let the producer waves update them (adamw_rows_pass), twice
@@ -588,15 +593,19 @@ DEVFN void pc_tile256(const GemmP& p, int64_t z, int wg, int ntn, int nwg, char*
   const DropKey dk = make_drop((p.epi & GSTVD_EPI_DROPOUT) ? p.p : 0.f, p.site, p.rng);
   if constexpr (sizeof(OT) == 2) {
     if (epilogue_rows_ok(p)) {
-      gemm_epilogue_rows<MI, NI, 4>(p, dk, acc, z, m0 + wm * WTM, n0 + wn * WTN, smem + wave * epi_wave_bytes<NI, 4>(), lane);
+      gemm_epilogue_rows<MI, NI, 4, (NIU >= 4)>(p, dk, acc, z, m0 + wm * WTM, n0 + wn * WTN, smem + wave * epi_wave_bytes<NI, 4>(), lane_e);
       return;
     }
   }
+  // (tile-wise fallback for unaligned operands: fresh opaque lane values per row block keep its 64-bit row / column indices from
+  // being computed up front and spilled at the 168-VGPR cap)
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+  for (int i = 0; i < MI; ++i) {
+    const int li_i = opaque_lane(li), g_i = opaque_lane(g);
 #pragma unroll
     for (int j = 0; j < NI; ++j)
-      gemm_epilogue_tile<bf16, OT>(p, dk, acc[i][j], z, m0 + wm * WTM + i * 16 + li, n0 + wn * WTN + j * 16 + 4 * g);
+      gemm_epilogue_tile<bf16, OT>(p, dk, acc[i][j], z, m0 + wm * WTM + i * 16 + li_i, n0 + wn * WTN + j * 16 + 4 * g_i);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -695,6 +704,7 @@ DEVFN void pc_tile256_nt64(const GemmP& p, int64_t z, int wg, int ntn, int nwg, 
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   int sa = 0, sb = 0;
+  {
   const int g = lane >> 4, li = lane & 15;
   for (int64_t t = 0; t < nkt; t += 2) {
     const char* cA = smem + sa * A_SLOT;
@@ -727,19 +737,24 @@ DEVFN void pc_tile256_nt64(const GemmP& p, int64_t z, int wg, int ntn, int nwg, 
     sa = (sa + 1 == 3) ? 0 : sa + 1;
     sb ^= 1;
   }
+  }
   __builtin_amdgcn_s_barrier();        // every producer has drained its DMAs, every consumer is done with the ring: LDS is free
+  const int lane_e = sizeof(OT) == 4 ? opaque_lane(lane) : lane;        // (see pc_tile256)
+  const int g = lane_e >> 4, li = lane_e & 15;
   const DropKey dk = make_drop((p.epi & GSTVD_EPI_DROPOUT) ? p.p : 0.f, p.site, p.rng);
   if constexpr (sizeof(OT) == 2) {
     if (epilogue_rows_ok(p)) {
-      gemm_epilogue_rows<MI, NI, 4>(p, dk, acc, z, m0 + wm * WTM, n0 + wn * WTN, smem + wave * epi_wave_bytes<NI, 4>(), lane);
+      gemm_epilogue_rows<MI, NI, 4, (NIU >= 4)>(p, dk, acc, z, m0 + wm * WTM, n0 + wn * WTN, smem + wave * epi_wave_bytes<NI, 4>(), lane_e);
       return;
     }
   }
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+  for (int i = 0; i < MI; ++i) {
+    const int li_i = opaque_lane(li), g_i = opaque_lane(g);
 #pragma unroll
     for (int j = 0; j < NI; ++j)
-      gemm_epilogue_tile<bf16, OT>(p, dk, acc[i][j], z, m0 + wm * WTM + i * 16 + li, n0 + wn * WTN + j * 16 + 4 * g);
+      gemm_epilogue_tile<bf16, OT>(p, dk, acc[i][j], z, m0 + wm * WTM + i * 16 + li_i, n0 + wn * WTN + j * 16 + 4 * g_i);
+  }
 }
 
 DEVFN int xcd_remap256(int bid, int nwg) {
@@ -791,6 +806,7 @@ __global__ __launch_bounds__(512) void gemm_dma256_grouped_kernel(const gstvd_ge
   const int entry = grouped_tile_id(bmap, total, chs);
   if (entry < 0) return;
   const int gid = entry & GROUP_TILE_MASK;
+  if (gid >= total) return;                  // a map entry that names no tile of the table (the host checks the map it builds; this keeps a bad one from writing)
   int lo = 0, hi = nprob - 1;
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tile_off[mid] <= gid) lo = mid; else hi = mid - 1; }
   const gstvd_gemm_t& g = tab[lo];
@@ -813,18 +829,15 @@ template <typename OT, bool AKM, bool BKM>
 static int launch256(const GemmP& p, int64_t batch, int niu, hipStream_t s) {
   auto k0 = gemm_dma256_kernel<OT, AKM, BKM, 0>;
   auto k3 = gemm_dma256_kernel<OT, AKM, BKM, 0, 3>;
+  static int attr_rc = ensure_lds(k0, LDS256) | ensure_lds(k3, LDS256);
+  if (attr_rc) return attr_rc;
+  // The K-step schedule variants that rounds 2-4 measured and rejected (ST = 4: all fragment reads first; the ping-pong tile;
+  // the timing ablations) exist only in the diagnostic build: GSTVD_DIAG_ST, GSTVD_DIAG_PP, GSTVD_DIAG_ABLATE.
+  int abl = 0, st = 0;
+#ifdef GSTVD_DIAG
   auto p0 = gemm_dma256_kernel<OT, AKM, BKM, 0, 4, 4>;
   auto p3 = gemm_dma256_kernel<OT, AKM, BKM, 0, 3, 4>;
   auto ke = gemm_dma256_kernel<OT, AKM, BKM, -5>;
-  static int attr_rc = ensure_lds(k0, LDS256) | ensure_lds(k3, LDS256) | ensure_lds(ke, LDS256) | ensure_lds(p0, LDS256) |
-                       ensure_lds(p3, LDS256);
-  if (attr_rc) return attr_rc;
-  // schedule selectors of the PRODUCT build -- every value computes correct results: GSTVD_GEMM_ST 0 / 4 (K-step schedule),
-  // GSTVD_GEMM_PP=1 the ping-pong tile (round 2's GSTVD_GEMM_ABLATE=5)
-  static const int st_env = [] { const char* e = getenv("GSTVD_GEMM_ST"); return e ? atoi(e) : 0; }();
-  static const int pp = [] { const char* e = getenv("GSTVD_GEMM_PP"); return e ? atoi(e) : 0; }();
-  int abl = pp ? 5 : 0, st = st_env == 4 ? 4 : 0;
-#ifdef GSTVD_DIAG
   auto c0 = gemm_dma256_kernel<OT, AKM, BKM, 0, 4, 3>;
   auto c1 = gemm_dma256_kernel<OT, AKM, BKM, -1, 4, 3>;
   auto c2 = gemm_dma256_kernel<OT, AKM, BKM, -2, 4, 3>;
@@ -836,11 +849,13 @@ static int launch256(const GemmP& p, int64_t batch, int niu, hipStream_t s) {
   auto kf = gemm_dma256_kernel<OT, AKM, BKM, -6>;
   static int diag_rc = ensure_lds(c0, LDS256) | ensure_lds(c1, LDS256) | ensure_lds(c2, LDS256) | ensure_lds(c7, LDS256) |
                        ensure_lds(c8, LDS256) | ensure_lds(p1, LDS256) | ensure_lds(ka, LDS256) | ensure_lds(kb, LDS256) |
-                       ensure_lds(kf, LDS256);
+                       ensure_lds(kf, LDS256) | ensure_lds(ke, LDS256) | ensure_lds(p0, LDS256) | ensure_lds(p3, LDS256);
   if (diag_rc) return diag_rc;
+  static const int st_env = [] { const char* e = getenv("GSTVD_DIAG_ST"); return e ? atoi(e) : 0; }();
+  static const int pp = [] { const char* e = getenv("GSTVD_DIAG_PP"); return e ? atoi(e) : 0; }();
   static const int diag_abl = [] { const char* e = getenv("GSTVD_DIAG_ABLATE"); return e ? atoi(e) : 0; }();
-  if (diag_abl) abl = diag_abl;
-  if (st_env == 3) st = 3;
+  abl = diag_abl ? diag_abl : (pp ? 5 : 0);
+  st = (st_env == 3 || st_env == 4) ? st_env : 0;
 #endif
   const int bnu = (niu == 3 && abl == 0) ? 192 : 256;
   const int ntm = (int)((p.M + 255) / 256), ntn = (int)((p.N + bnu - 1) / bnu);
@@ -873,10 +888,11 @@ static int launch256(const GemmP& p, int64_t batch, int niu, hipStream_t s) {
     GSTVD_LAUNCH_CHECK();
     return 0;
   }
-  auto kern = st == 4 ? (bnu == 192 ? p3 : p0) : abl == 5 ? ke : (bnu == 192 ? k3 : k0);
+  auto kern = bnu == 192 ? k3 : k0;
 #ifdef GSTVD_DIAG
-  if (st == 4 && abl == 1) kern = p1;
+  if (st == 4) kern = abl == 1 ? p1 : (bnu == 192 ? p3 : p0);
   else if (st == 3) kern = abl == 1 ? c1 : abl == 2 ? c2 : abl == 7 ? c7 : abl == 8 ? c8 : c0;
+  else if (abl == 5) kern = ke;
   else if (abl == 1) kern = ka;
   else if (abl == 2) kern = kb;
   else if (abl == 6) kern = kf;
@@ -897,8 +913,6 @@ static int launch256_layout(const GemmP& p, int64_t batch, int akm, int bkm, int
 // Tile width: 256 columns, or 192 when that needs fewer rounds of 256 CUs for the work it does.  Cost model from the
 // measured kernel: ~14 us fixed + 0.95 us per 32-deep K step for the full tile, ~0.9x that per step for the 192 one.
 static int pick_niu(const GemmP& p, int64_t batch) {
-  static const int force = [] { const char* e = getenv("GSTVD_GEMM256_NIU"); return e ? atoi(e) : 0; }();
-  if (force == 3 || force == 4) return force;
   const double nkt = (double)((p.K + 31) / 32), ntm = (double)((p.M + 255) / 256);
   const double t4 = ntm * (double)((p.N + 255) / 256) * batch, t3 = ntm * (double)((p.N + 191) / 192) * batch;
   const double r4 = (double)(int64_t)((t4 + 255) / 256), r3 = (double)(int64_t)((t3 + 255) / 256);
@@ -907,9 +921,7 @@ static int pick_niu(const GemmP& p, int64_t batch) {
 
 // Single-problem policy: the big tile only pays when its (4x smaller) grid still covers most of the chip.
 int gemm_dma256_dispatch(const GemmP& p, int64_t batch, int akm, int bkm, int out_f32, hipStream_t s) {
-  static const int variant = [] { const char* e = getenv("GSTVD_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
   static const int min_tiles = [] { const char* e = getenv("GSTVD_GEMM256_MIN_TILES"); return e ? atoi(e) : 120; }();
-  if (variant == 1 || variant == 2 || variant == 4) return GSTVD_E_UNSUPPORTED;
   const int64_t tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256) * batch;
   if (p.M < 256 || p.N < 256 || tiles < min_tiles) return GSTVD_E_UNSUPPORTED;
   const int niu = pick_niu(p, batch);
@@ -923,6 +935,7 @@ __global__ __launch_bounds__(768) void gemm_pc256_grouped_kernel(const gstvd_gem
   const int entry = grouped_tile_id(bmap, total, chs);
   if (entry < 0) return;
   const int gid = entry & GROUP_TILE_MASK;
+  if (gid >= total) return;                  // a map entry that names no tile of the table (the host checks the map it builds; this keeps a bad one from writing)
   int lo = 0, hi = nprob - 1;
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tile_off[mid] <= gid) lo = mid; else hi = mid - 1; }
   const gstvd_gemm_t& g = tab[lo];
@@ -943,6 +956,7 @@ __global__ __launch_bounds__(768) void gemm_pc256_grouped_adamw_kernel(const gst
   const int entry = grouped_tile_id(bmap, total, chs);
   if (entry < 0) return;
   const int gid = entry & GROUP_TILE_MASK;
+  if (gid >= total) return;                  // a map entry that names no tile of the table (the host checks the map it builds; this keeps a bad one from writing)
   int lo = 0, hi = nprob - 1;
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tile_off[mid] <= gid) lo = mid; else hi = mid - 1; }
   const gstvd_gemm_t& g = tab[lo];
@@ -960,16 +974,14 @@ __global__ __launch_bounds__(768) void gemm_pc256_grouped_adamw_kernel(const gst
 template <typename OT, bool AKM, bool BKM>
 static int grouped256(const gstvd_gemm_t* tab, const int* off, int nprob, int total, const int* bmap, int nblocks, hipStream_t s) {
   auto k0 = gemm_dma256_grouped_kernel<OT, AKM, BKM, 0>;
-  auto k4 = gemm_dma256_grouped_kernel<OT, AKM, BKM, 0, 4>;
-  static int attr_rc = ensure_lds(k0, LDS256) | ensure_lds(k4, LDS256);
+  static int attr_rc = ensure_lds(k0, LDS256);
   if (attr_rc) return attr_rc;
-  static const int st = [] { const char* e = getenv("GSTVD_GEMM_ST"); return (e && atoi(e) == 4) ? 4 : 0; }();
   // tiles per XCD chunk = 2^chs (default 8: measured best of 1..128 inside the step); GSTVD_GROUP_CHUNK_LOG2 overrides for tuning runs
   static const int chs = [] { const char* e = getenv("GSTVD_GROUP_CHUNK_LOG2"); const int v = e ? atoi(e) : 3; return v < 0 ? 0 : (v > 10 ? 10 : v); }();
   // weight gradients are long-K problems (K = rows of the batch): the producer / consumer tile gains ~0.08 us on every one of
   // their ~128 K-steps (18432x768x4688: 160 -> 143 us)
   static const int pc = [] { const char* e = getenv("GSTVD_GEMM_PC"); return e ? atoi(e) : 1; }();
-  if (pc && st == 0) {
+  if (pc) {
     auto kp = gemm_pc256_grouped_kernel<OT, AKM, BKM>;
     static int pc_rc = ensure_lds(kp, LDS256);
     if (pc_rc) return pc_rc;
@@ -977,7 +989,7 @@ static int grouped256(const gstvd_gemm_t* tab, const int* off, int nprob, int to
     GSTVD_LAUNCH_CHECK();
     return 0;
   }
-  GSTVD_LAUNCH(st == 4 ? k4 : k0, dim3((unsigned)(bmap ? nblocks : total)), dim3(512), LDS256, s, tab, off, nprob, total, chs, bmap);
+  GSTVD_LAUNCH(k0, dim3((unsigned)(bmap ? nblocks : total)), dim3(512), LDS256, s, tab, off, nprob, total, chs, bmap);
   GSTVD_LAUNCH_CHECK();
   return 0;
 }
@@ -986,9 +998,7 @@ extern "C" int gstvd_gemm_group_tile(void) { return 256; }
 
 extern "C" int32_t gstvd_gemm_group_caps(void) {
   const char* e = getenv("GSTVD_GEMM_PC");
-  const char* t = getenv("GSTVD_GEMM_ST");
-  const bool pc = (e ? atoi(e) : 1) != 0 && (t ? atoi(t) : 0) != 4;
-  return pc ? 1 : 0;
+  return (e ? atoi(e) : 1) != 0 ? 1 : 0;
 }
 
 // symbol of the grouped kernel for a (dtype, layout) combination -- same plan-only mechanism as gstvd_gemm_kernel_name
@@ -1033,7 +1043,7 @@ extern "C" int gstvd_gemm_grouped_adamw(const gstvd_gemm_t* table_dev, const int
   if (!table_dev || !tile_off_dev || !f) return GSTVD_E_NULL;
   if (!f->grad_base || !f->param || !f->m || !f->v || !f->step) return GSTVD_E_NULL;
   if (nprob <= 0 || total_tiles <= 0) return GSTVD_E_SHAPE;
-  if (block_map_dev && nblocks < total_tiles) return GSTVD_E_SHAPE;     // a map that cannot name every tile
+  if (block_map_dev && (nblocks < total_tiles || total_tiles > GROUP_TILE_MASK)) return GSTVD_E_SHAPE;     // a map that cannot name every tile
   if (((uintptr_t)f->grad_base | (uintptr_t)f->param | (uintptr_t)f->m | (uintptr_t)f->v | (uintptr_t)f->shadow_bf16) & 15) return GSTVD_E_ALIGN;
   if (!(gstvd_gemm_group_caps() & 1)) return GSTVD_E_UNSUPPORTED;     // the producer / consumer tile is switched off (tuning runs)
   auto kp = gemm_pc256_grouped_adamw_kernel;
@@ -1051,7 +1061,7 @@ extern "C" int gstvd_gemm_grouped(const gstvd_gemm_t* table_dev, const int32_t* 
                                   const int32_t* block_map_dev, int64_t nblocks, gstvd_stream_t stream) {
   if (!table_dev || !tile_off_dev) return GSTVD_E_NULL;
   if (nprob <= 0 || total_tiles <= 0) return GSTVD_E_SHAPE;
-  if (block_map_dev && nblocks < total_tiles) return GSTVD_E_SHAPE;     // a map that cannot name every tile
+  if (block_map_dev && (nblocks < total_tiles || total_tiles > GROUP_TILE_MASK)) return GSTVD_E_SHAPE;     // a map that cannot name every tile
   if (dtype_in != GSTVD_BF16) return GSTVD_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   const int n = (int)nprob, t = (int)total_tiles, nb = (int)nblocks;

@@ -141,8 +141,9 @@ __global__ __launch_bounds__(NT) void sample_topk_kernel(gstvd_sample_t a) {
       if (n >= (float)a.top_k) lo = mid; else hi = mid;
     }
     kth = fkey_inv(lo);
-  } else if (a.top_k > 0) {
-    const int k = a.top_k < V ? a.top_k : V;
+  } else if (a.top_k > 0 && a.top_k < V) {                     // (top_k >= V filters nothing -- the reference clamps k to V and
+    const int k = a.top_k;                                   //  keeps everything >= the row's minimum: kth stays -inf.  Walking
+                                                             //  V distinct values, one block reduction each, did the same slowly)
     int have = c;
     float thr = m;
     while (have < k) {                                       // uniform: every thread holds the same (thr, have)

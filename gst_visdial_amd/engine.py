@@ -34,7 +34,7 @@ from .config import encoder_schedule
 from ._lib import GstvdError, EPI_GELU, EPI_DGELU, LN_RESID, LN_EMBED, LN_IMAGE
 
 
-EARLY_WGRAD = int(os.environ.get("GSTVD_EARLY_WGRAD", "1"))     # 0: the final grouped weight-gradient launch waits for the embedding backward (A/B)
+EARLY_WGRAD = 1     # 0 (tests / tools patch the attribute): the final grouped weight-gradient launch waits for the embedding backward
 
 
 def _round_up(x, m):
@@ -347,6 +347,7 @@ class Engine(object):
         self._decode_sessions = {}
         self._last_decode = None
         self.anchor = None
+        self._emb_span_ok = {}
         self.pipe = None               # BackwardPipeline (pipeline.py): slice-wise wgrad / all-reduce / AdamW on the aux stream
         self.tape, self.rec = [], False
         self.accumulate, self.written = False, set()
@@ -488,7 +489,7 @@ class Engine(object):
         backward reaches the encoder's text embedding -- what is left is that embedding's backward (scatter-adds, 33 us), and the
         column reductions of the LayerNorm / bias gradients (47 us): inputs of the REMAINDER AdamW pass, not of the grouped
         launch.  So the grouped launch starts here on the auxiliary stream and those two run beside it instead of in front of it
-        (GSTVD_EARLY_WGRAD=0: the launch waits for them, as in rounds 4-5a)."""
+        (engine.EARLY_WGRAD = 0: the launch waits for them, as in rounds 4-5a; profiles/r05_early_wgrad_ab.txt)."""
         p = self.pipe
         if not self.use_streams or p is None or p.hi is None or p.slices or p.hi != self.flat.n_live or p.fuse_handle() is None:
             return
@@ -744,7 +745,15 @@ class Engine(object):
             # no parameter): one fill instead of four dependent ones on the backward chain
             lo = self.flat.slots[prefix + ".word"][0]
             hi = self.flat.slots[prefix + ".tte"][0] + tabs[3].numel()
-            if not (0 <= hi - lo <= sum(t.numel() for t in tabs) + self.flat.Vp * H + 4 * 64):
+            ok = self._emb_span_ok.get((prefix, lo, hi))
+            if ok is None:
+                # no OTHER parameter's slot may start inside the span (its finished gradient would be wiped): checked against the
+                # layout itself, once per layout, instead of against a size bound with a whole padded table of slack
+                mine = set(prefix + n for n in (".word", ".pos", ".tt", ".tte"))
+                own = set(self.flat.slots[n][0] for n in mine)
+                ok = hi >= lo and all(not (lo <= off < hi) or off in own for name, (off, _) in self.flat.slots.items() if name not in mine)
+                self._emb_span_ok[(prefix, lo, hi)] = ok
+            if not ok:
                 raise GstvdError("internal: embedding tables are not contiguous in the flat buffer")
             self.flat.G[lo:hi].zero_()
         else:
@@ -930,7 +939,7 @@ class Engine(object):
             self.tape.append(("t", self._flush_aux))      # backward: the decoder's gradients are complete here
         kv_on_side = False
         if kv is None:
-            if self.use_streams and os.environ.get("GSTVD_KV_SIDE", "1") != "0":
+            if self.use_streams:
                 # the cross-attention K/V of all layers (one 4688 x 18432 x 768 GEMM, 0.19 ms; its input gradient as much) goes
                 # to the side stream, idle since the encoder joined: it runs beside the decoder's embedding and the first layer's
                 # self-attention sub-layer, and in backward its input gradient beside what is left of the decoder's backward

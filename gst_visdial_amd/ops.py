@@ -222,9 +222,11 @@ def _splitk_scratch(device):
     return ws
 
 
-# 0: the library's own chunked order (rounds 1-4); 1: per-XCD queues of whole units; 2: + staggered lead-in; 3 (default): the queues
-# in ROUNDS of an XCD's 32 CUs with short-K fillers; 4: rounds with 30-tile pieces (xcd_block_map)
-GROUP_ORDER = int(os.environ.get("GSTVD_GROUP_ORDER", "3"))
+# Tile placement of the grouped launches (xcd_block_map): 3 = per-XCD queues in ROUNDS of an XCD's 32 CUs with short-K fillers
+# for the fused weight-gradient + AdamW launch, plain per-XCD queues of whole units (mode 1) for the unfused launch of the N > 1
+# path.  0 = the library's own chunked order (rounds 1-4; tests compare against it).  Round 5's other candidates (staggered
+# lead-in, 30-tile pieces) were measured and are gone: profiles/r05_group_order_ab.txt, r05_group_rounds_ab.txt.
+GROUP_ORDER = 3
 N_XCD = 8
 XCD_CUS = 32                                # CUs of one XCD = workgroups of the 139 KB-LDS grouped kernels it runs at a time
 GROUP_ORDER_MIN_TILES = 4 * N_XCD * 32      # a few rounds of the chip at least: below that the order is moot (tests lower it)
@@ -242,25 +244,20 @@ def xcd_block_map(shapes, tile, fused_epilogue, mode=1, unit_tiles=40):
     Here: (1) a problem (or, for the few large ones, a contiguous range of <= `unit_tiles` of its tiles) is a UNIT that goes to
     one XCD whole; (2) units are sorted into classes of equal K -- equal running time -- long K first, and dealt to the XCD
     with the least work so far (LPT), so every queue is long-K units back to back, then the short ones: tiles that start
-    together finish together and the next 32 start together again; (3) mode 2: XCD x first runs x/8 of a long tile's time
-    worth of SHORT units -- the eight XCDs then sit in different phases of the K-loop / epilogue cycle, and one XCD's
-    HBM-bound AdamW epilogues (fused launch) run under the other XCDs' MFMA-bound K-loops instead of all at once.
+    together finish together and the next 32 start together again; (3) mode 3: the queue is cut into ROUNDS (below).
     `shapes`: [(M, N, K)] per problem in table order; tile ids follow tile_off (problem after problem)."""
     T = tile
-    rounds = mode in (3, 4)
-    if mode == 3:
+    if mode not in (1, 3):
+        raise ValueError("xcd_block_map: mode 1 (queues of whole units) or 3 (rounds with short-K fillers)")
+    rounds = mode == 3
+    if rounds:
         unit_tiles = min(unit_tiles, XCD_CUS - 5)    # 27: a unit must fit one round of an XCD's CUs with room for a few fillers
-    if mode == 4:
-        unit_tiles = XCD_CUS - 2                     # 30: large problems are cut into pieces of 30 tiles + a remainder (36 = 30 + 6)
     units = []                                   # (K, first tile id, number of tiles)
     gid = 0
     for (M, N, K) in shapes:
         nt = ((M + T - 1) // T) * ((N + T - 1) // T)
-        if mode == 4:
-            sizes = [unit_tiles] * (nt // unit_tiles) + ([nt % unit_tiles] if nt % unit_tiles else [])
-        else:
-            parts = max(1, (nt + unit_tiles - 1) // unit_tiles)
-            sizes = [nt // parts + (1 if i < nt % parts else 0) for i in range(parts)]
+        parts = max(1, (nt + unit_tiles - 1) // unit_tiles)
+        sizes = [nt // parts + (1 if i < nt % parts else 0) for i in range(parts)]
         t0 = gid
         for n in sizes:
             units.append((K, t0, n))
@@ -283,15 +280,6 @@ def xcd_block_map(shapes, tile, fused_epilogue, mode=1, unit_tiles=40):
             load[x] += cost(u[0], u[2])
     queues = []
     for x in range(N_XCD):
-        lead = []
-        if mode == 2 and ql[x] and qs[x]:
-            t_long = cost(ql[x][0][0], 1)
-            want = t_long * x / N_XCD            # us of lead-in on this XCD
-            got = 0.0
-            while qs[x] and got + 1e-9 < want:
-                u = qs[x].pop()                  # from the end: the shortest units
-                lead.append(u)
-                got += cost(u[0], u[2]) / 32.0   # ~32 tiles of an XCD run at a time
         q = []
         if rounds and ql[x]:
             # ROUNDS (round 5, second half): an XCD runs XCD_CUS = 32 of these workgroups at a time (139 KB of LDS: one per CU), and
@@ -320,7 +308,7 @@ def xcd_block_map(shapes, tile, fused_epilogue, mode=1, unit_tiles=40):
                 si += nf
             q.extend(shorts[si:])
         else:
-            for (_, t0, n) in lead + ql[x] + qs[x]:
+            for (_, t0, n) in ql[x] + qs[x]:
                 q.extend(range(t0, t0 + n))
         queues.append(q)
     depth = max(len(q) for q in queues)
@@ -451,9 +439,13 @@ class GemmGroup(object):
                 # (rounds with fillers pay in the FUSED launch, whose tiles carry 50 us epilogues and which runs near the fabric's
                 # rate: 13.50 -> 13.15 GB, -2.6 %; the plain launch of the N > 1 path is not bound by bytes and fetches less with
                 # whole 36-tile units: 3.44 vs 3.86 GB stand-alone, profiles/r05_group_rounds_ab.txt)
-                mode = 1 if (GROUP_ORDER == 3 and fuse is None) else GROUP_ORDER
-                bmap = torch.tensor(xcd_block_map([(it[3], it[4], it[5]) for it in key], T, fuse is not None, mode),
-                                    dtype=torch.int32).to(self.device)
+                mode = 3 if fuse is not None else 1
+                bm_host = xcd_block_map([(it[3], it[4], it[5]) for it in key], T, fuse is not None, mode)
+                # the C side's contract -- every tile id exactly once, the rest idle (-1) -- is checked HERE, where the map is
+                # made (once per cached table): an id out of range would compute a tile past its problem's extent
+                if sorted(t for t in bm_host if t >= 0) != list(range(tiles)) or any(t < -1 for t in bm_host):
+                    raise L.GstvdError("internal: block map is not a placement of the launch's %d tiles" % tiles)
+                bmap = torch.tensor(bm_host, dtype=torch.int32).to(self.device)
             hit = (tab, off, len(key), tiles, flops, nbytes, bmap)
             if len(self.cache) > 64:
                 self.cache.clear()
@@ -648,7 +640,7 @@ def locgrad(dh, loc, M, H, dw_loc, accumulate):
                                                _stream()))
 
 
-KEEP_BITS = int(os.environ.get("GSTVD_ATTN_KEEP_BITS", "1"))     # 0: the backward hashes its dropout draws again (A/B)
+KEEP_BITS = 1     # 0 (tests / tools patch the attribute): the backward hashes its dropout draws again (profiles/r05_attn_keep_bits_ab.txt)
 
 
 def attn_keep_bits_shape(B, nh, Lq, Lk, d, dtype, causal, drop_p):
@@ -878,13 +870,13 @@ def gemm_ln_bwd(ln_kw, dy, partial, nblk, B, C_out, N, *, dres=None, dx=None, b_
     return C_out
 
 
-LN_FOLD_MAX_H = int(os.environ.get("GSTVD_LN_FOLD_MAX_H", "768"))
+LN_FOLD_MAX_H = 768
 
 
 def gemm_ln_ok(M, N, H, dtype):
     """Shapes the engine gives to the LayerNorm-folded GEMMs (csrc/gemm_rows.hip): bf16, H = K a multiple of 64 up to
-    GSTVD_LN_FOLD_MAX_H = 768 (the decoder's sites), up to 640 rows (beyond that the plain kernels' larger tiles win), at least
-    five 128-column tiles.  The kernel itself takes H up to 1024 since round 5 (the vision stream's width; GSTVD_LN_FOLD_MAX_H=1024
+    ops.LN_FOLD_MAX_H = 768 (the decoder's sites), up to 640 rows (beyond that the plain kernels' larger tiles win), at least
+    five 128-column tiles.  The kernel itself takes H up to 1024 since round 5 (the vision stream's width; LN_FOLD_MAX_H = 1024
     sends its 36 sites there): bit-identical, but an 80 KB / 512-thread workgroup does not fit beside the text stream's
     workgroups the way the 48 KB 64-tile GEMM + the LayerNorm kernel do -- 12.35 -> 12.66 ms per step
     (profiles/r05_ln_fold_vision_ab.txt), so the default keeps the vision sites on the separate kernels."""

@@ -24,7 +24,7 @@ SHAPES = [(768, 768, 400), (3072, 768, 1000), (300, 64, 37), (1024, 1024, 592), 
           (768, 768, 1000), (3072, 768, 400), (256, 256, 400), (1024, 2048, 592), (64, 3072, 256), (768, 1024, 1000)]
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [3])
 def test_grouped_launch_results_do_not_depend_on_the_block_map(mode, monkeypatch):
     """gstvd_gemm_grouped with block_map_dev: every tile of every problem runs exactly once whatever the order -- dW and the bias
     column sums are bit-identical to the library's own order (same per-tile arithmetic), incl. ragged shapes and idle blocks."""
