@@ -208,8 +208,9 @@ def cpu_baseline(model, T, R, U, F, V, rows=2):
     """The oracle (parity-checked port of the reference) on the host cores: forward + loss + backward, fp32, TRAIN mode.
 
     BASELINE.md section 4's procedure: model.train() (the oracle's `train=True`: F.dropout on the host RNG at every one of the
-    reference's dropout sites -- 11 % of the reference's own CPU time is bernoulli_), 1 untimed warm-up + 3 timed steps of the
-    same sample, MEDIAN reported, thread count and logical-CPU count printed.  One deviation, stated in the line: the thread count
+    reference's dropout sites -- 11 % of the reference's own CPU time is bernoulli_), 1 untimed warm-up + 5 timed steps of the
+    same sample (round 6: 5 instead of 3 -- the only CPU figure of the line swung 20 % between rounds), MEDIAN reported with the
+    min-max spread, thread count and logical-CPU count printed.  One deviation, stated in the line: the thread count
     is min(os.cpu_count(), 16), not os.cpu_count() -- eager fp32 PyTorch on the 256-thread GPU-box host collapses with every
     logical CPU in the pool (measured 900 s for 2 rows with 256 threads)."""
     from gst_visdial_amd.config import bert_base_enc_config, bert_base_dec_config
@@ -227,11 +228,12 @@ def cpu_baseline(model, T, R, U, F, V, rows=2):
         return time.perf_counter() - t0
 
     one(1, 16)                                     # thread-pool / allocator warm-up (tiny, untimed)
-    t1 = one(1, T)                                 # sizing probe: how many rows fit ~5 s per timed step (so 1 + 3 steps stay ~20 s)
-    n = max(1, min(32, int(5.0 / max(t1, 1e-3))))
+    t1 = one(1, T)                                 # sizing probe: how many rows fit ~4 s per timed step (so 1 + 5 steps stay ~25 s)
+    n = max(1, min(32, int(4.0 / max(t1, 1e-3))))
     one(n, T)                                      # the procedure's warm-up step (untimed)
-    times = sorted(one(n, T) for _ in range(3))
-    dt = times[1]                                  # median of 3
+    times = sorted(one(n, T) for _ in range(5))
+    dt = times[2]                                  # median of 5
+    spread = (times[-1] - times[0]) / dt
     cpu_model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
@@ -239,10 +241,11 @@ def cpu_baseline(model, T, R, U, F, V, rows=2):
     except OSError:
         pass
     return {"value": n / dt, "unit": "dialog-rounds/sec", "cores": threads, "kind": "port", "cpu_model": cpu_model,
-            "host_logical_cpus": os.cpu_count(), "mode": "train (dropout on, host RNG)", "timed_steps": 3, "warmup_steps": 1,
-            "step_seconds": [round(t, 2) for t in times],
-            "sample": "%d row(s) x (1 warm-up + 3 timed) train steps (fwd+loss+bwd, fp32, dropout on, T=%d R=%d U=%d) of oracle/vd_oracle.py "
-                      "on %d of %d logical CPUs; median %.1f s per step" % (n, T, R, U, threads, os.cpu_count() or 0, dt)}
+            "host_logical_cpus": os.cpu_count(), "mode": "train (dropout on, host RNG)", "timed_steps": 5, "warmup_steps": 1,
+            "step_seconds": [round(t, 2) for t in times], "spread_of_median": round(spread, 3),
+            "sample": "%d row(s) x (1 warm-up + 5 timed) train steps (fwd+loss+bwd, fp32, dropout on, T=%d R=%d U=%d) of oracle/vd_oracle.py "
+                      "on %d of %d logical CPUs (eager fp32 PyTorch collapses with all of them in the pool); median %.1f s per step, "
+                      "min-max spread of the 5 steps %.0f %% of the median" % (n, T, R, U, threads, os.cpu_count() or 0, dt, 100 * spread)}
 
 
 def eval_decode_side(device, V):
@@ -353,12 +356,17 @@ def main():
     ap.add_argument("--legs", default="auto", choices=["auto", "on", "off"],
                     help="extra N>1 legs beside the headline, each in fresh child processes: 10 rows/rank (BASELINE configs[2]) and the "
                          "reference-faithful fp32 gradient all-reduce (auto: when more than one rank runs)")
+    ap.add_argument("--no-rows-sensitivity", action="store_true",
+                    help="skip the 32 / 64 rows-per-GPU side runs (fresh child processes; never `value`) that separate 'the kernels cannot' "
+                         "from '16 rows per GPU is too small' for north_star's co-attention target")
     ap.add_argument("--leg", default=None, help=argparse.SUPPRESS)          # set by run_leg(): this process IS a leg's rank
     args = ap.parse_args()
     argv = sys.argv[1:]
 
     if args.leg is not None:             # a leg's rank: the timed region only, no side measurements, no legs of its own
-        args.no_breakdown = args.no_cpu_baseline = args.no_h2d = args.no_fp32 = args.no_eval_decode = True
+        keep_breakdown = args.leg.startswith("rows_sens")       # (the rows-sensitivity children exist FOR the per-kernel breakdown)
+        args.no_breakdown = args.no_breakdown or not keep_breakdown
+        args.no_cpu_baseline = args.no_h2d = args.no_fp32 = args.no_eval_decode = args.no_rows_sensitivity = True
         args.legs = "off"
 
     # ---- launcher: `--gpus N` with N > 1 and no rank environment -> start the N ranks ourselves (child process, no GPU call here)
@@ -660,6 +668,23 @@ def main():
                 break
             except (OSError, ValueError):
                 continue
+        # the committed rocprofv3 --kernel-trace --stats average of the SAME kernel inside replayed steps (profiles/rNN_kernel_stats_bench.csv):
+        # the serialized eager pass above reads 2-7 % slower than that (profiles/r05_bench_repeat.txt), so the two are printed side by side
+        rocprof_us, rocprof_src = None, None
+        for fn in ("r06_kernel_stats_bench.csv", "r05_kernel_stats_bench.csv"):
+            try:
+                import csv as _csv
+                with open(os.path.join(ROOT, "profiles", fn)) as f:
+                    for r in _csv.DictReader(f):
+                        nm = r.get("Name", "")
+                        if nm == dom or nm == (demangle(dom) or "") or ("grouped_adamw" in dom and "grouped_adamw" in nm):
+                            rocprof_us = round(float(r["AverageNs"]) / 1e3, 2)
+                            break
+                if rocprof_us is not None:
+                    rocprof_src = "profiles/%s (rocprofv3 --kernel-trace --stats of bench.py, committed; not measured in this run)" % fn
+                    break
+            except (OSError, ValueError, KeyError):
+                continue
         others = [{"kernel": k, "achieved": round(gemms[k]["flops"] / (gemms[k]["ms"] * 1e-3) / 1e12, 2),
                    "frac": round(gemms[k]["flops"] / (gemms[k]["ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                    "ms_per_step": round(gemms[k]["ms"], 3)} for k in order[1:3]]
@@ -678,6 +703,9 @@ def main():
         roofline.update({"traffic": traffic, "traffic_source": traffic_src,
                     "kernel": dom, "kernel_demangled": demangle(dom), "launches_per_step": dv["launches"],
                     "flops_per_launch": dv["flops"] / dv["launches"], "avg_launch_us": round(1e3 * dv["ms"] / dv["launches"], 2),
+                    "avg_launch_us_rocprof": rocprof_us, "avg_launch_us_rocprof_source": rocprof_src,
+                    "frac_at_rocprof_duration": (round(dv["bytes"] / dv["launches"] / (rocprof_us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)
+                                                 if (rocprof_us and dv["bytes"] and t_hbm > t_mfma) else None),
                     "algorithmic_bytes_per_launch": (dv["bytes"] / dv["launches"]) if dv["bytes"] else None,
                     "all_gemm_tflops": round(all_gemm_flops / (all_gemm_ms * 1e-3) / 1e12, 2),
                     "all_gemm_ms_per_step": round(all_gemm_ms, 3),
@@ -793,6 +821,29 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(model, T, R, U, F, V)
 
+    # ---- rows sensitivity: the same step at 32 and 64 rows per GPU, each in a fresh child process; a SIDE
+    # record (never `value`): step_frac / coattn_frac / all_gemm_tflops per row count
+    rows_sens = None
+    if (rank == 0 and world == 1 and not force_dist and args.leg is None and B == 16 and args.precision == "bf16" and roofline is not None
+            and not args.no_rows_sensitivity):
+        rows_sens = {"16": {"ms_per_step": round(ms_step, 3), "rounds_per_s": round(rows_s, 1), "step_frac": roofline.get("step_frac"),
+                            "coattn_frac": roofline.get("coattn_frac"), "all_gemm_tflops": roofline.get("all_gemm_tflops")}}
+        import subprocess              # (288 GB of HBM: the children fit beside this process's model)
+        for rr in (32, 64):
+            cmd = [sys.executable, os.path.abspath(__file__), "--rows-per-gpu", str(rr), "--steps", "5", "--warmup", "2", "--no-cpu-baseline",
+                   "--no-eval-decode", "--no-fp32", "--no-h2d", "--no-rows-sensitivity", "--leg", "rows_sens%d" % rr]
+            try:
+                r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300)
+                line, _ = parse_last_json(r.stdout.decode("utf-8", "replace"))
+                rf = (line or {}).get("roofline") or {}
+                rows_sens[str(rr)] = ({"ms_per_step": line.get("ms_per_step"), "rounds_per_s": round(line.get("value"), 1), "step_frac": rf.get("step_frac"),
+                                       "coattn_frac": rf.get("coattn_frac"), "all_gemm_tflops": rf.get("all_gemm_tflops")}
+                                      if line and r.returncode == 0 else {"error": "child exit code %d" % r.returncode})
+            except Exception as ex:        # noqa: BLE001 -- a side record must not take the line down
+                rows_sens[str(rr)] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+        rows_sens["reading"] = ("coattn_frac = bf16 MFMA utilisation of the 6 connection layers' forward + input-gradient GEMMs (north_star: >= 0.40); "
+                                "never `value`: the headline stays BASELINE configs[1]'s 16 rows per GPU")
+
     if rank == 0:
         out = {"metric": "dialog-rounds/sec (enc_dec_a train step)", "value": round(rows_s, 3), "unit": "dialog-rounds/sec",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
@@ -827,6 +878,7 @@ def main():
                                            "scaling_vs_n1": "value(N) / value(1) at equal rows_per_gpu; bench.py never reports efficiency itself"}
         from gst_visdial_amd import graph as _g
         out["config"]["capture_quiesce"] = _g.LAST_QUIESCE[0] if use_graph else None
+        out["config"]["rows_sensitivity"] = rows_sens
         out["config"]["fp32_parity_mode_ms_per_step"] = fp32_ms
         out["config"]["pcie_inclusive"] = pcie
         out["config"]["decode"] = (side or {}).get("decode") if side and "error" not in side else side
