@@ -143,8 +143,8 @@ def run_leg(name, extra, base_argv, rank, world, local, port, timeout=420):
         r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, timeout=timeout)
     except subprocess.TimeoutExpired:
         return {"error": "leg %s: no result within %d s" % (name, timeout)}
-    if rank != 0:
-        return None
+    if rank != 0:       # (every rank of a leg exits with the same code: its ranks agree on success through a collective before they time)
+        return None if r.returncode == 0 else {"error": "leg %s: child exit code %d" % (name, r.returncode)}
     line, _ = parse_last_json(r.stdout.decode("utf-8", "replace"))
     if r.returncode != 0 or line is None:
         return {"error": "leg %s: child exit code %d%s" % (name, r.returncode, "" if line else ", no JSON line")}
@@ -339,7 +339,7 @@ def main():
     ap.add_argument("--grad-compress", default="auto", choices=["auto", "none", "bf16"],
                     help="dtype of the gradient all-reduce payload (auto: bf16 for N>1 -- halves xGMI traffic; fp32 master grads kept)")
     ap.add_argument("--breakdown-json", default=None, help="write the per-kernel breakdown here")
-    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off", "segmented"],
                     help="replay the whole train step as one hipGraph (auto = on at every N: at N>1 the RCCL all-reduces are captured "
                          "with the step and a failed capture is a hard error; off: eager issue, host bound)")
     ap.add_argument("--no-pipeline", action="store_true", help="diagnostic: no backward pipeline (wgrad/AdamW after backward, same stream)")
@@ -428,7 +428,7 @@ def main():
             enable_watchdog_introspection()      # lets the capture wait until c10d's watchdog has retired the warm-up collectives
             dist.init_process_group("nccl", device_id=device)
         # ports for the child legs, agreed on while the group is young and healthy (nothing is issued on it after a failed capture)
-        ports = [[_free_port() for _ in range(4)] if rank == 0 else None]
+        ports = [[_free_port() for _ in range(6)] if rank == 0 else None]
         dist.broadcast_object_list(ports, src=0)
         leg_ports.extend(int(p) for p in ports[0])
 
@@ -507,10 +507,38 @@ def main():
     # more than the GPU needs to execute them.  At N>1 the RCCL all-reduces of the backward pipeline are captured with the
     # rest of the step (stream capture of RCCL collectives, as used for graph-mode serving on this stack); if capture is
     # refused the run falls back to eager issue and says so in config.hip_graph.
-    use_graph = args.graph in ("on", "auto")
+    use_graph = args.graph in ("on", "auto", "segmented")
+    # `--graph segmented` (or GSTVD_FORCE_SEGMENTED=1 with the default `auto`): the N > 1 fall-back form -- one hipGraph per gradient
+    # slice, the slices' collectives and updates issued eagerly between the replays (graph.SegmentedStep)
+    segmented = (world > 1 or force_dist) and pipe is not None and (args.graph == "segmented" or (args.graph == "auto" and os.environ.get("GSTVD_FORCE_SEGMENTED", "0") == "1"))
+    if args.graph == "segmented" and not segmented:
+        sys.stderr.write("bench: --graph segmented needs the N > 1 path (a collective): world %d, GSTVD_FORCE_DIST %s\n" % (world, force_dist))
+        sys.exit(2)
     for _ in range(max(args.warmup, 2) if use_graph else args.warmup):
         loss = step()
-    if use_graph:
+    if use_graph and segmented:
+        from gst_visdial_amd.graph import SegmentedStep
+        try:
+            replay = SegmentedStep(device_step, pipe, warmup=0)
+        except Exception as ex:          # noqa: BLE001
+            capture_error = "%s: %s" % (type(ex).__name__, ex)
+            torch.cuda.synchronize()
+        import torch.distributed as dist
+        ok = torch.tensor([0.0 if capture_error else 1.0], device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) < 1.0:
+            sys.stderr.write("bench: segmented capture of the train step failed on %s (%s)\n" % ("this rank" if capture_error else "another rank", capture_error))
+            dist.destroy_process_group()
+            sys.exit(3)
+
+        def step():                  # noqa: F811
+            loss = replay()
+            host_step_end()
+            return loss
+        use_graph = "segmented"
+        for _ in range(args.warmup):
+            loss = step()
+    elif use_graph:
         # Capture one full step (forward, backward on both HIP streams, pipelined all-reduce + fused AdamW) and replay it:
         # same kernels, same work, no host in the loop.  Device-resident state (dropout offset, AdamW step counter)
         # advances inside the graph.
@@ -534,7 +562,7 @@ def main():
                 sys.stderr.write("bench: hipGraph capture of the train step failed on %s (%s)\n"
                                  % ("this rank" if capture_error else "another rank", capture_error))
                 if args.graph == "on" or args.leg is not None:
-                    sys.stderr.write("bench: --graph on: refusing to time the host-bound eager path\n")
+                    sys.stderr.write("bench: --graph on: refusing to time another path\n")
                     dist.destroy_process_group()
                     sys.exit(3)
                 capture_error = capture_error or "capture failed on another rank"
@@ -545,12 +573,20 @@ def main():
                     dist.destroy_process_group()
                 except Exception:          # noqa: BLE001
                     pass
-                fb = run_leg("eager_fallback", ["--graph", "off"], argv, rank, world, local, leg_port(0))
+                # first the SEGMENTED form (one graph per gradient slice, collectives eager between them: the same kernels at ~40 host
+                # calls per step), then -- if that capture is refused as well -- eager issue (host bound, ~19 ms per step)
+                fb = run_leg("segmented_fallback", ["--graph", "segmented"], argv, rank, world, local, leg_port(0))
+                how = "fresh child processes after the failed whole-step hipGraph capture: SEGMENTED replay (graph.SegmentedStep)"
+                if fb is not None and "error" in fb:       # (rank > 0: None = its child exited 0; the ranks of a leg fail together)
+                    if rank == 0:
+                        sys.stderr.write("bench: the segmented fall-back failed too (%s); timing eager issue\n" % fb.get("error"))
+                    fb = run_leg("eager_fallback", ["--graph", "off"], argv, rank, world, local, leg_port(5))
+                    how = "fresh child processes after the failed hipGraph captures (whole step and segmented): eager issue, host bound"
                 rc = 3
                 if rank == 0:
                     if fb and "error" not in fb:
                         fb.setdefault("config", {})["capture_error"] = capture_error
-                        fb["config"]["measured_in"] = "fresh child processes after the failed hipGraph capture (eager issue, host bound)"
+                        fb["config"]["measured_in"] = how
                         fb["config"].pop("leg", None)
                         _flush_c_stdio()
                         print(json.dumps(fb), flush=True)
@@ -854,7 +890,7 @@ def main():
                                       % (B, T, "BASELINE configs[1] per-GPU shape" if B == 16 else
                                          "BASELINE configs[2] per-rank shape (global 80 at 8 GPUs)" if B == 10 else "custom rows/GPU"),
                           "global_batch": B * world, "rows_per_gpu": B, "seq_len": T, "parallelism": "dp%d" % world, "leg": args.leg,
-                          "gpu_ms_per_step_events": round(e0.elapsed_time(e1) / args.steps, 3), "eager_host_issue_ms_per_step": round(host_ms, 3), "hip_graph": bool(use_graph), "capture_error": capture_error_msg,
+                          "gpu_ms_per_step_events": round(e0.elapsed_time(e1) / args.steps, 3), "eager_host_issue_ms_per_step": round(host_ms, 3), "hip_graph": (use_graph if use_graph == "segmented" else bool(use_graph)), "graphs_per_step": (getattr(replay, "n_graphs", 1) if use_graph else 0), "capture_error": capture_error_msg,
                           "final_loss": round(final_loss, 4)},
                "roofline": roofline, "cpu_baseline": cpu}
         if breakdown is not None:

@@ -390,6 +390,7 @@ class Engine(object):
         embedding aliasing of train_gen.py:293) and make sure the bf16 shadow weights are current."""
         if device.type != "cuda":
             raise GstvdError("gst_visdial_amd runs on MI355X only; tensors are on %s (no CPU path)" % device)
+        ops.set_device(device)
         gen = self.model.decoder.decoder
         topo = (id(gen.bert.embeddings), id(self.model.encoder.bert_pretrained.bert.embeddings), id(gen.lm_head.decoder.weight))
         if self.flat is None or self.flat.topo != topo:
@@ -506,6 +507,26 @@ class Engine(object):
 
     def _emit(self, off):
         """Hand the finished slice [off, pipe.hi) to the backward pipeline on the auxiliary stream."""
+        if getattr(self.pipe, "segmenter", None) is not None:
+            # Segmented capture (graph.SegmentedStep: the fall-back when a whole-step capture WITH its collectives is refused): the
+            # slice's collective is issued eagerly BETWEEN two captured graphs, so the capture is cut here.  A capture can only end
+            # with every forked stream joined into its origin: the vision stream joins, the slice's weight gradients and column
+            # reductions run on the main stream (beside the backward chain they are zero-sum anyway), run_slice cuts, and the vision
+            # stream is forked into the next capture at once -- its next tape entry may come before the next recorded dependency,
+            # and a launch on a stream outside the capture would run at capture time instead of being captured.
+            if self.use_streams:
+                self._wait("t", "v")
+                if self.aux_busy:
+                    ev = torch.cuda.Event()
+                    ev.record(self.aux)
+                    self.main.wait_event(ev)
+                    self.aux_busy = False
+            fused = self.wgrads.flush(fuse=self.pipe.fuse_handle())
+            self.colsums.flush()
+            self.pipe.run_slice(off, self.pipe.hi, fused=fused)
+            if self.use_streams:
+                self._wait("v", "t")
+            return
         for src in ([self.main, self.side] if self.use_streams else [self.main]):
             ev = torch.cuda.Event()
             ev.record(src)

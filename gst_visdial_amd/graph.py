@@ -144,3 +144,89 @@ class GraphedStep(object):
     def __call__(self):
         self.graph.replay()
         return self.out
+
+
+class SegmentedStep(object):
+    """The step as a SEQUENCE of hipGraphs with the collectives issued eagerly between them -- the fall-back for a refused
+    whole-step capture at N > 1 (RCCL inside a stream capture has only ever been seen working with ONE rank on this stack), so that
+    the first contact with 8 GPUs does not depend on one capture succeeding.  Eager issue costs ~19 ms of host time per step for
+    ~12 ms of GPU work; this form costs the host one replay per gradient slice plus the slices' collectives and updates (~40
+    calls), with the same kernels on the device.
+
+    How: `pipe.segmenter = self` while `step_fn` runs under a capture that this object opens by hand.  At every slice boundary the
+    engine joins its streams into the capture's origin stream (Engine._emit) and BackwardPipeline.run_slice calls `cut(fn)`: the
+    open capture ends (one more graph), `fn` -- fork to the communication stream, cast, all-reduce / reduce-scatter, AdamW, record
+    the tail event -- is filed as an eager item and NOT run (nothing has executed yet: a collective here would reduce garbage),
+    and the next capture opens from the same memory pool.  Replay = the items in order; a last item joins the communication stream.
+    What is lost against the whole-step graph: a slice's weight-gradient launch runs in line on the main stream instead of
+    beside the backward chain (zero-sum at full-chip kernels), and the update of slice k is issued by the
+    host while segment k + 1 is already replaying.  Same requirements as GraphedStep (static addresses, inputs refreshed in place)."""
+
+    def __init__(self, step_fn, pipe, warmup=2):
+        if pipe is None or not pipe.collective:
+            raise ValueError("SegmentedStep is the N > 1 fall-back: it needs a BackwardPipeline with a collective")
+        self.pipe, self.items, self._cur, self.pool = pipe, [], None, None
+        for _ in range(warmup):
+            self.out = step_fn()
+        quiesce_before_capture()
+        # "relaxed": loss.backward() runs the tape on autograd's device thread, so the cuts -- hipStreamEndCapture / BeginCapture --
+        # happen on a different thread than the first BeginCapture; only a relaxed-mode capture may be ended from another thread
+        # (hipErrorStreamCaptureWrongThread otherwise).  Relaxed also lets c10d's watchdog query its events meanwhile.
+        self._mode = "relaxed"
+        self.stream = torch.cuda.Stream()
+        pipe.segmenter = self
+        try:
+            with gc_quiet():
+                torch.cuda.synchronize()
+                self.stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self.stream):
+                    self._open()
+                    try:
+                        self.out = step_fn()
+                    except BaseException:
+                        self._abort()
+                        raise
+                    self._close()
+                torch.cuda.current_stream().wait_stream(self.stream)
+        finally:
+            pipe.segmenter = None
+        self.items.append(("call", pipe.segment_join))
+        self.n_graphs = sum(1 for k, _ in self.items if k == "graph")
+
+    def _open(self):
+        g = torch.cuda.CUDAGraph()
+        if self.pool is None:
+            self.pool = torch.cuda.graph_pool_handle()
+        g.capture_begin(pool=self.pool, capture_error_mode=self._mode)
+        self._cur = g
+
+    def _close(self):
+        import warnings
+        with warnings.catch_warnings():
+            # the segment behind the LAST cut holds host work only (optimizer bookkeeping): "The CUDA Graph is empty" is expected there
+            warnings.filterwarnings("ignore", message="The CUDA Graph is empty")
+            self._cur.capture_end()
+        self.items.append(("graph", self._cur))
+        self._cur = None
+
+    def _abort(self):
+        if self._cur is not None:
+            try:
+                self._cur.capture_end()
+            except Exception:          # noqa: BLE001 -- the capture is already invalid; the original error is what matters
+                pass
+            self._cur = None
+
+    def cut(self, fn):
+        """Called by BackwardPipeline.run_slice on the capture's origin stream, every forked stream joined."""
+        self._close()
+        self.items.append(("call", fn))
+        self._open()
+
+    def __call__(self):
+        for kind, x in self.items:
+            if kind == "graph":
+                x.replay()
+            else:
+                x()
+        return self.out

@@ -27,7 +27,22 @@ def _p(t):
     return t.data_ptr()
 
 
+# The handle of the current HIP stream is needed by every library call (~330 per eagerly issued step).  The public route --
+# torch.cuda.current_stream().cuda_stream -- builds a Stream object and resolves the device index through four Python layers:
+# 2.55 us per call, 0.85 ms of host time per step (tools/host_profile.py, profiles/r06_host_profile.txt).  torch's own raw
+# accessor returns the same handle in ~0.2 us; the engine tells this module which device it drives (one per process).
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_DEV_INDEX = None
+
+
+def set_device(device):
+    global _DEV_INDEX
+    _DEV_INDEX = device.index if device.index is not None else torch.cuda.current_device()
+
+
 def _stream():
+    if _RAW_STREAM is not None and _DEV_INDEX is not None:
+        return _RAW_STREAM(_DEV_INDEX)
     return torch.cuda.current_stream().cuda_stream
 
 

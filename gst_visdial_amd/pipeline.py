@@ -70,6 +70,10 @@ class BackwardPipeline(object):
         self.fuse_update = os.environ.get("GSTVD_FUSE_UPDATE", "1") != "0"
         if optimizer is not None:
             optimizer.grad_scale = 1.0 / self.world
+        # graph.SegmentedStep sets this while it captures: a slice's collective (+ update) is then NOT issued into the open capture;
+        # run_slice hands it to segmenter.cut(fn), which closes the capture, files `fn` as an eagerly issued item of the replay
+        # sequence and opens the next capture (the fall-back for a refused whole-step capture at N > 1: VERDICT r5 item 3a)
+        self.segmenter = None
         self._skip_next = self._skipping = False
         self._stale = set()           # flat offsets of the weights whose gradient the LAST backward never stored (fused update)
         engine.pipe = self
@@ -154,7 +158,21 @@ class BackwardPipeline(object):
                     self.tail_event.record(self.comm)
             else:
                 self._update(lo, hi, None, fused)
-        elif self.shard_update and self.opt is not None:
+        elif self.segmenter is not None:
+            if not sl.is_cuda:
+                raise RuntimeError("segmented capture needs device tensors")
+            self.segmenter.cut(lambda lo=lo, hi=hi: self._collective_slice(lo, hi))
+        else:
+            self._collective_slice(lo, hi)
+        self.hi = lo
+
+    def _collective_slice(self, lo, hi):
+        """A finished slice's collective and update, issued on the CURRENT stream's behalf: (device tensors, the default) the work
+        forks onto the communication stream and leaves its last event in `tail_event`; host tensors / GSTVD_PIPE_COMM=0 run in line.
+        Called from run_slice, or -- segmented replay -- eagerly between two captured segments of the step."""
+        flat = self.engine.flat
+        sl = flat.G[lo:hi]
+        if self.shard_update and self.opt is not None:
             if sl.is_cuda and self.use_comm_stream:
                 if self.comm is None:
                     self.comm = torch.cuda.Stream(device=sl.device)
@@ -206,7 +224,12 @@ class BackwardPipeline(object):
                 self._update(lo, hi, reduced)
                 self.tail_event = torch.cuda.Event()
                 self.tail_event.record(self.comm)
-        self.hi = lo
+
+    def segment_join(self):
+        """Last item of a segmented replay: the current stream waits for the communication stream's last slice."""
+        ev, self.tail_event = self.tail_event, None
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
 
     def _update(self, lo, hi, reduced, fused=()):
         if reduced is not None and (self.opt is None or self.keep_grads):
