@@ -75,7 +75,6 @@ def test_segmented_replay_equals_the_whole_step_graph(train, compress, shard):
         # same kernels on the same data; the embedding tables' gradients are atomic scatter-adds (their order is not fixed)
         for a, b in ((pg, ps), (mg, ms), (vg, vs)):
             assert (a - b).abs().max().item() < 1e-6
-            assert (a != b).float().mean().item() < 1e-3
     finally:
         if created:
             dist.destroy_process_group()
