@@ -473,7 +473,8 @@ def main():
         chunk_elems = 1 << 40
     pipe = None if args.no_pipeline else BackwardPipeline(model.engine, optimizer=opt, chunk_elems=chunk_elems,
                                                           compress=compress, force_collective=force_dist,
-                                                          shard_update=(args.shard_update == "on" and (world > 1 or force_dist)))
+                                                          shard_update=(args.shard_update == "on" and (world > 1 or force_dist)),
+                                                          direct_bf16=os.environ.get("GSTVD_BENCH_DIRECT_BF16", "1") != "0")
 
     def device_step():
         """Everything of a train step that is device work -- the part that is captured into the hipGraph."""
@@ -904,6 +905,8 @@ def main():
                                              else "sharded: reduce-scatter -> AdamW on the rank's 1/N shard -> all-gather of the bf16 shadow weights"
                                              if (pipe.shard_update and pipe.collective) else "AdamW pass per gradient slice (full, on every rank)")
         out["config"]["gradient_slices_per_step"] = len(pipe.slices) if pipe is not None else None
+        # N > 1, bf16 payload: the weight-gradient launch writes the payload of the GEMM weights itself; only the rest of a slice is cast
+        out["config"]["payload_written_by_wgrad_launch"] = bool(pipe is not None and pipe.Gb is not None and any(len(k[2]) for k in pipe._cast_plans))
         # what the communicator really is (N>1 only runs on the driver's node: this is the evidence that it was RCCL, over how
         # many ranks, with which payload); summing bf16 payloads IN bf16 deviates from the reference's fp32 reduce-add by
         # <= 4e-3 of a tensor's norm at 8 ranks (tests/test_dp_gloo.py::test_eight_rank_graded_slices_bf16_payload_error_bound)

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgstvd_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 F32, BF16 = 0, 1
 EPI_BIAS, EPI_ADD, EPI_GELU, EPI_DGELU, EPI_DROPOUT = 1, 2, 4, 8, 16
@@ -113,6 +113,7 @@ SIGNATURES = {
     "gstvd_sample_topk": (_i32, [C.POINTER(SampleDesc), _vp]),
     "gstvd_vl_split": (_i32, [_vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _f32, _u32, _u32, _vp, _vp]),
     "gstvd_cast": (_i32, [_vp, _i32, _vp, _i32, _i64, _vp]),
+    "gstvd_cast_ranges": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp]),
     "gstvd_scale": (_i32, [_vp, _vp, _i64, _vp]),
     "gstvd_rng_advance": (_i32, [_vp, _vp]),
     "gstvd_dropout_mask": (_i32, [_vp, _i64, _f32, _u32, _vp, _vp]),

@@ -108,6 +108,18 @@ __global__ __launch_bounds__(256) void cast_kernel(const S* src, Dt* dst, int64_
   else for (int64_t j = i; j < n; ++j) dst[j] = from_f<Dt>(to_f(src[j]));
 }
 
+// fp32 -> bf16 over a LIST of ranges of two flat buffers with the same indexing (gstvd_cast_ranges): block b serves 1024 elements
+// of the range whose block interval [blk0[i], blk0[i + 1]) holds it
+__global__ __launch_bounds__(256) void cast_ranges_kernel(const float* src, bf16* dst, const int64_t* tab, const int32_t* blk0, int n) {
+  const int b = blockIdx.x;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (blk0[mid] <= b) lo = mid; else hi = mid - 1; }
+  const int64_t start = tab[2 * lo], len = tab[2 * lo + 1];
+  const int64_t i = ((int64_t)(b - blk0[lo]) * 256 + threadIdx.x) * 4;
+  if (i + 3 < len) st4(dst + start + i, ld4(src + start + i));
+  else for (int64_t j = i; j < len; ++j) dst[start + j] = (bf16)src[start + j];
+}
+
 __global__ void scale_kernel(float* x, const float* f, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) x[i] *= f[0];
@@ -202,7 +214,7 @@ extern "C" int gstvd_vl_split(const void* d_enc, int64_t B, int64_t R, int64_t T
 
 // 2: gstvd_ln_bwd_t.nblk (round 2); 3: gstvd_gemm_ln_fwd / _bwd, debug entry gone (round 3); 4: gstvd_gemm_grouped_adamw,
 // gstvd_adamw_blocks (round 4); 5: block_map_dev / nblocks of the grouped launches (round 5)
-extern "C" int gstvd_abi_version(void) { return 6; }
+extern "C" int gstvd_abi_version(void) { return 7; }
 extern "C" const char* gstvd_build_arch(void) { return "gfx950"; }
 
 extern "C" int gstvd_ce_fwd(const void* logits, int64_t ldl, const int64_t* labels, int64_t M, int64_t V, int64_t ignore_index,
@@ -255,6 +267,17 @@ extern "C" int gstvd_cast(const void* src, int32_t sdt, void* dst, int32_t ddt, 
   else if (sdt == GSTVD_F32 && ddt == GSTVD_F32) hipLaunchKernelGGL((cast_kernel<float, float>), grid, dim3(256), 0, s, (const float*)src, (float*)dst, n);
   else if (sdt == GSTVD_BF16 && ddt == GSTVD_BF16) hipLaunchKernelGGL((cast_kernel<bf16, bf16>), grid, dim3(256), 0, s, (const bf16*)src, (bf16*)dst, n);
   else return GSTVD_E_DTYPE;
+  GSTVD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gstvd_cast_ranges(const float* src, void* dst_bf16, const int64_t* ranges_dev, const int32_t* blk0_dev, int64_t nranges,
+                                 int64_t total_blocks, gstvd_stream_t stream) {
+  if (!src || !dst_bf16 || !ranges_dev || !blk0_dev) return GSTVD_E_NULL;
+  if (nranges <= 0 || total_blocks <= 0 || nranges > (1 << 24)) return GSTVD_E_SHAPE;
+  if (((uintptr_t)src & 15) || ((uintptr_t)dst_bf16 & 7)) return GSTVD_E_ALIGN;
+  hipLaunchKernelGGL(cast_ranges_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, src, (bf16*)dst_bf16, ranges_dev, blk0_dev,
+                     (int)nranges);
   GSTVD_LAUNCH_CHECK();
   return 0;
 }

@@ -505,6 +505,14 @@ class Engine(object):
         self._early = True
         self.aux_busy = True
 
+    def _flush_wgrads(self):
+        """The slice's queued weight gradients: -> (fused, direct).  N = 1: one launch that also applies AdamW (`fused` offsets).
+        N > 1 with a bf16 payload: the launch writes the payload itself (`direct` ranges, pipeline.bf16_target)."""
+        tgt = self.pipe.bf16_target()
+        if tgt is not None:
+            return (), self.wgrads.flush_direct_bf16(*tgt)
+        return self.wgrads.flush(fuse=self.pipe.fuse_handle()), ()
+
     def _emit(self, off):
         """Hand the finished slice [off, pipe.hi) to the backward pipeline on the auxiliary stream."""
         if getattr(self.pipe, "segmenter", None) is not None:
@@ -521,9 +529,9 @@ class Engine(object):
                     ev.record(self.aux)
                     self.main.wait_event(ev)
                     self.aux_busy = False
-            fused = self.wgrads.flush(fuse=self.pipe.fuse_handle())
+            fused, direct = self._flush_wgrads()
             self.colsums.flush()
-            self.pipe.run_slice(off, self.pipe.hi, fused=fused)
+            self.pipe.run_slice(off, self.pipe.hi, fused=fused, direct=direct)
             if self.use_streams:
                 self._wait("v", "t")
             return
@@ -552,7 +560,7 @@ class Engine(object):
             # j+1, also with the weight-gradient launch confined to 160-224 CUs: 13.73-14.01 ms against 13.72 ms, resp. +0.3 ms --
             # the two full-chip kernels do not share the chip profitably; profiles/r03_chunk_sweep.txt.  Not kept.)
             with torch.cuda.stream(self.aux):
-                fused = self.wgrads.flush(fuse=self.pipe.fuse_handle())
+                fused, direct = self._flush_wgrads()
             # (issuing these reductions from the vision stream instead does not let the grouped launch start earlier:
             # 12.30 / 12.34 vs 12.31 / 12.35 ms, tools/r05_s14.sh)
             self.colsums.flush()
@@ -560,12 +568,12 @@ class Engine(object):
             ev.record(self.main)
             self.aux.wait_event(ev)
             with torch.cuda.stream(self.aux):
-                self.pipe.run_slice(off, self.pipe.hi, fused=fused)
+                self.pipe.run_slice(off, self.pipe.hi, fused=fused, direct=direct)
         else:
             with torch.cuda.stream(self.aux):
-                fused = self.wgrads.flush(fuse=self.pipe.fuse_handle())
+                fused, direct = self._flush_wgrads()
                 self.colsums.flush()
-                self.pipe.run_slice(off, self.pipe.hi, fused=fused)
+                self.pipe.run_slice(off, self.pipe.hi, fused=fused, direct=direct)
         self.aux_busy = True
 
     # -- two HIP streams: the vision stream's skinny (M = B*37) kernels run beside the text stream's --------------

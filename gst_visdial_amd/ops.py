@@ -384,6 +384,37 @@ class GemmGroup(object):
                 reach, owner = hi, i
         return bad
 
+    def flush_direct_bf16(self, G, Gb):
+        """The N > 1 path with a bf16 gradient payload: every queued weight gradient that is the ONLY contribution to its weight
+        this step is written by the launch ITSELF in bf16 into `Gb` (the flat bf16 buffer the slice's collective sends, indexed
+        like the fp32 gradient buffer `G`) instead of in fp32 into G -- the fp32 store (4 B per weight) and the cast pass that would
+        read it back (4 B) never happen; the rounding is the cast's (round to nearest even of the fp32 accumulator), so the payload
+        is bit-identical.  The other problems (accumulating, or sharing their block with another writer: the tied LM head) stay
+        fp32.  Two launches instead of one.  Returns the flat (offset, numel) ranges written in bf16, sorted."""
+        if not self.items or self.dtype_in != BF16 or self.dtype_out != F32 or not (self.a_km and self.b_km):
+            self.flush()
+            return ()
+        base, nG = G.data_ptr(), G.numel()
+        shared = self._overlapping(self.items)
+        direct, rest, keep_d, keep_r, ranges = [], [], [], [], []
+        for i, (it, kp) in enumerate(zip(self.items, self.keep)):
+            (a, b, c, M, N, K, lda, ldb, ldc, acc) = it[:10]
+            off = (c - base) // 4
+            if acc or i in shared or ldc != N or c < base or off + M * N > nG or (c - base) % 4 or off % 8:
+                rest.append(it); keep_r.append(kp)
+            else:
+                direct.append(it[:2] + (Gb.data_ptr() + 2 * off,) + it[3:]); keep_d.append(kp)
+                ranges.append((off, M * N))
+        self.items, self.keep = rest, keep_r
+        self.flush()
+        if direct:
+            self.items, self.keep, self.dtype_out = direct, keep_d, BF16
+            try:
+                self.flush()
+            finally:
+                self.dtype_out = F32
+        return tuple(sorted(ranges))
+
     def flush(self, fuse=None):
         """Launch the queued problems.  `fuse` (optim.FusedAdamW.fuse_handle(), single-GPU training only): every queued weight
         gradient that is the ONLY contribution to its weight this step gets GSTVD_EPI_ADAMW -- the launch updates the weight in
@@ -783,6 +814,32 @@ def cast(src, dst, n=None):
     n = src.numel() if n is None else n
     L.check("gstvd_cast", lib.gstvd_cast(_p(src), dt(src), _p(dst), dt(dst), n, _stream()))
     return dst
+
+
+class CastRanges(object):
+    """A fixed list of ranges [(start, length)] of two flat buffers with the same indexing, uploaded once (gstvd_cast_ranges)."""
+
+    def __init__(self, ranges, device):
+        self.ranges = [(int(a), int(n)) for a, n in ranges if n > 0]
+        if any(a % 4 for a, _ in self.ranges):
+            raise L.GstvdError("cast_ranges: range starts must be multiples of 4 elements")
+        blk0, b = [], 0
+        for _, n in self.ranges:
+            blk0.append(b)
+            b += (n + 1023) // 1024
+        blk0.append(b)
+        self.blocks, self.elems = b, sum(n for _, n in self.ranges)
+        flat = [v for r in self.ranges for v in r]
+        self.tab = torch.tensor(flat, dtype=torch.int64).to(device) if flat else None
+        self.blk0 = torch.tensor(blk0, dtype=torch.int32).to(device)
+
+    def run(self, src, dst):
+        """dst[e] = bf16(src[e]) over the ranges; src fp32, dst bf16, both indexed alike."""
+        if not self.ranges:
+            return
+        lib = L.load()
+        L.check("gstvd_cast_ranges", lib.gstvd_cast_ranges(_p(src), _p(dst), self.tab.data_ptr(), self.blk0.data_ptr(), len(self.ranges),
+                                                           self.blocks, _stream()))
 
 
 def scale_(x, factor):

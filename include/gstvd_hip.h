@@ -281,6 +281,13 @@ int gstvd_vl_split(const void* d_enc, int64_t B, int64_t R, int64_t T, int64_t H
 
 /* ---- element-wise plumbing --------------------------------------------------------------------*/
 int gstvd_cast(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t n, gstvd_stream_t s);
+/* (ABI 7) dst[e] = bf16(src[e]) for e in the union of `nranges` ranges of two flat buffers that share their indexing: ranges_dev =
+ * device int64[nranges][2] (start, length; start % 4 == 0), blk0_dev = device int32[nranges + 1], the exclusive prefix sum of the
+ * ranges' block counts ceil(length / 1024); total_blocks = blk0_dev[nranges].  The N > 1 gradient path: the weight-gradient
+ * launch writes the bf16 all-reduce payload of every GEMM weight itself, this casts the REST of a slice (biases, LayerNorm, embedding
+ * tables: ~5 % of it) instead of a pass over the whole fp32 gradient buffer (train_gen.py:324: the reduce-add of DataParallel). */
+int gstvd_cast_ranges(const float* src, void* dst_bf16, const int64_t* ranges_dev, const int32_t* blk0_dev, int64_t nranges,
+                      int64_t total_blocks, gstvd_stream_t s);
 int gstvd_scale(float* x, const float* factor, int64_t n, gstvd_stream_t s);   /* x *= factor[0] */
 int gstvd_rng_advance(uint64_t* rng, gstvd_stream_t s);                        /* rng[1] += 1 */
 /* materialise a dropout mask (1/(1-p) or 0) for tests: out[e] for e in [0, n) */

@@ -89,3 +89,78 @@ def test_segmented_step_refuses_a_pipeline_without_a_collective():
     pipe = BackwardPipeline(model.engine, optimizer=opt)
     with pytest.raises(ValueError):
         SegmentedStep(lambda: None, pipe)
+
+
+# ---- N > 1 with a bf16 payload: the weight-gradient launch writes the payload itself -------------------------
+def test_cast_ranges_matches_the_plain_cast_on_its_ranges_and_leaves_the_rest_alone():
+    from gst_visdial_amd import ops as o
+    n = 300000
+    g = torch.Generator().manual_seed(1)
+    src = torch.randn(n, generator=g).to(DEV)
+    ranges = [(0, 4), (64, 1000), (2048, 1024), (8192, 5), (65536, 70000), (n - 12, 12)]
+    dst = torch.full((n,), 7.0, device=DEV, dtype=torch.bfloat16)
+    plan = o.CastRanges(ranges, torch.device(DEV))
+    plan.run(src, dst)
+    want = torch.full((n,), 7.0, device=DEV, dtype=torch.bfloat16)
+    ref = torch.empty(n, device=DEV, dtype=torch.bfloat16)
+    o.cast(src, ref)
+    for a, m in ranges:
+        want[a:a + m] = ref[a:a + m]
+    assert torch.equal(dst, want) and plan.elems == sum(m for _, m in ranges)
+    o.CastRanges([], torch.device(DEV)).run(src, dst)             # nothing to do is not an error
+    with pytest.raises(Exception):
+        o.CastRanges([(2, 8)], torch.device(DEV))
+
+
+@pytest.mark.parametrize("shard", [False, True], ids=["allreduce", "sharded_update"])
+def test_direct_bf16_payload_is_bit_identical_to_store_then_cast(shard):
+    """bf16 mode, 1-rank RCCL group: with direct_bf16 the grouped weight-gradient launch writes the all-reduce payload of every GEMM
+    weight in bf16 and only the rest of a slice is cast; the rounding is the cast's, so parameters, moments and shadows are BIT-identical
+    to the store-fp32-then-cast path -- eagerly and under graph replay.  `.grad` of a weight whose fp32 gradient was never stored is None."""
+    import torch.distributed as dist
+    from gst_visdial_amd.optim import FusedAdamW
+    from gst_visdial_amd.pipeline import BackwardPipeline
+    from gst_visdial_amd.graph import GraphedStep
+    s = sc()
+    g = load_npz("tiny_train.npz")
+    created = _group()
+    try:
+        def run(direct, graphed):
+            model, params, cfg = s.build_tiny_model("bf16", DEV, seed=3, cfg_file="tiny_cfg_dropout.json")
+            model.train()
+            kw = s.golden_batch(g, DEV)
+            opt = FusedAdamW(model, lr=1e-3)
+            pipe = BackwardPipeline(model.engine, optimizer=opt, chunk_elems=100000, compress="bf16", force_collective=True, shard_update=shard,
+                                    direct_bf16=direct)
+
+            def step():
+                loss, _ = model(**kw)
+                loss.backward()
+                none = sum(1 for p in model.engine.flat.live if p.grad is None)
+                opt.step()
+                opt.zero_grad()
+                return loss, none
+
+            for _ in range(2):
+                loss, none = step()
+            fn = (lambda f=GraphedStep(lambda: step()[0], warmup=0): f()) if graphed else (lambda: step()[0])
+            for _ in range(3):
+                loss = fn()
+            torch.cuda.synchronize()
+            eng = model.engine
+            return loss.item(), eng.flat.P.clone(), eng.flat.S.clone(), opt.m.clone(), opt.v.clone(), none, pipe
+
+        ref = run(False, False)
+        for graphed in (False, True):
+            got = run(True, graphed)
+            assert got[0] == ref[0]
+            for a, b in zip(ref[1:5], got[1:5]):
+                assert torch.equal(a, b)
+        assert ref[5] == 0 and got[5] > 20                       # the GEMM weights' `.grad` is None in direct mode (never stored in fp32)
+        pipe = got[6]
+        assert pipe.Gb is not None and any(len(k[2]) > 0 for k in pipe._cast_plans)
+        cast_elems = sum(pl[0].elems for pl in pipe._cast_plans.values())
+        assert cast_elems < 0.6 * pipe.Gb.numel()               # (tiny model: embeddings dominate; at full size the cast covers ~7 %)
+    finally:
+        if created:
+            dist.destroy_process_group()
