@@ -696,7 +696,7 @@ def main():
         pmc_key = lambda sym: ("gemm_grouped_adamw_256" if "grouped_adamw" in sym else "gemm_grouped_wgrad_256" if "grouped" in sym else "gemm_pc256" if "pc256" in sym else "gemm_dma256" if "gemm_dma256" in sym
                                else "gemm_dma128" if "Li128ELi128E" in sym else "gemm_dma64")
         traffic, traffic_src = None, None
-        for fn in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for fn in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:   # HBM bytes per launch from the committed PMC passes (tools/pmc_bench.sh; FETCH_SIZE x2 gfx950 correction +
                    # WRITE_SIZE): an average over the launches of the same tile CLASS, read from a file -- not measured in this run
                 with open(os.path.join(ROOT, "profiles", fn)) as f:

@@ -17,7 +17,8 @@ names = {"bench_n1.json": "bench_n1.json", "breakdown_events.json": "breakdown_e
          "attention_study.txt": "attention_study.txt", "ring_depth_ab.txt": "ring_depth_ab.txt",
          "bench_launch_paths.txt": "bench_launch_paths.txt", "bench_force_dist_legs.json": "bench_force_dist_legs.json",
          "cold_operands.txt": "cold_operands.txt", "step_ab.txt": "step_ab.txt", "bench_wall.txt": "bench_wall.txt",
-         "fused_update_bench.txt": "fused_update_bench.txt", "overlap_stats.txt": "overlap_stats.txt", "rccl_soak.txt": "rccl_soak.txt"}
+         "fused_update_bench.txt": "fused_update_bench.txt", "overlap_stats.txt": "overlap_stats.txt", "rccl_soak.txt": "rccl_soak.txt",
+         "timeline_dist.txt": "timeline_dist.txt", "bench_repeat.txt": "bench_repeat.txt"}
 for a, b in names.items():
     p = os.path.join(src, a)
     if os.path.exists(p):
