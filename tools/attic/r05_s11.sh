@@ -21,3 +21,5 @@ for v in 0 1; do
   f=$(ls $out/prof$v/*/*kernel_stats.csv | head -1); head -4 $f | tee -a $out/ab.txt; cp $f $out/kernel_stats_pf$v.csv; rm -rf $out/prof$v
 done
 cp $L/libgstvd_hip_pf1.so $L/libgstvd_hip.so
+#  the line above left the L2-PREFETCH build -- measured slower, not adopted -- in place of the default library on the box it ran on;
+# harmless there (a gpurun box is thrown away), but do not run this record against a checkout you keep: rebuild with `make -C gst_visdial_amd/csrc` afterwards.
