@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Back-to-back attention forward / backward at one of the step's shapes (for rocprofv3 --pmc / timing).
-usage: attn_probe.py B nh Lq Lk d [causal] [p_drop] [reps]"""
+usage: attn_probe.py B nh Lq Lk d [causal] [p_drop] [reps] [bits]     (bits = 1: forward leaves its dropout keep bits for backward, as in the step)"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
@@ -17,7 +17,10 @@ dQ, dK, dV = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
 lse = torch.empty(B * nh * Lq, device=dev); delta = torch.empty_like(lse)
 mask = torch.ones(B, Lk, device=dev); mask[:, int(0.8 * Lk):] = 0
 rng = ops.Rng(torch.device(dev), seed=1)
-a = ops.attn_desc(Q, K, V, O, lse, mask, B, nh, Lq, Lk, d, causal=causal, mask_neg=-10000.0, drop_p=p, site=5, rng=rng)
+use_bits = len(sys.argv) > 9 and int(sys.argv[9]) != 0
+nbits = ops.attn_keep_bits_shape(B, nh, Lq, Lk, d, torch.bfloat16, causal, p) if use_bits else 0
+bits = torch.zeros(nbits, device=dev, dtype=torch.int64) if nbits else None
+a = ops.attn_desc(Q, K, V, O, lse, mask, B, nh, Lq, Lk, d, causal=causal, mask_neg=-10000.0, drop_p=p, site=5, rng=rng, drop_bits=bits)
 def t(fn):
     for _ in range(3): fn()
     torch.cuda.synchronize()
@@ -29,4 +32,4 @@ def t(fn):
 tf = t(lambda: ops.attn_fwd(a))
 tb = t(lambda: ops.attn_bwd(a, dO, dQ, dK, dV, delta))
 fl = 4.0 * B * nh * Lq * Lk * d
-print("attn B=%d nh=%d Lq=%d Lk=%d d=%d causal=%d p=%.2f: fwd %.1f us (%.0f TF/s)  bwd %.1f us (%.0f TF/s)" % (B, nh, Lq, Lk, d, causal, p, tf, fl / tf / 1e6, tb, 3.5 * fl / tb / 1e6))
+print("attn B=%d nh=%d Lq=%d Lk=%d d=%d causal=%d p=%.2f bits=%d: fwd %.1f us (%.0f TF/s)  bwd %.1f us (%.0f TF/s)" % (B, nh, Lq, Lk, d, causal, p, int(bits is not None), tf, fl / tf / 1e6, tb, 3.5 * fl / tb / 1e6))
